@@ -1,0 +1,276 @@
+"""CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liboracle.so (built from oracle/oracle.c by
+`make -C oracle`).  Only tests/, __graft_entry__.smoke() and the cpu_baseline
+leg of bench.py may import this package; the product package never does.
+
+All 16-bit float tensors cross this boundary as numpy uint16 bit patterns,
+fp8 as uint8.  dt: 0 = bf16, 1 = fp16.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+BF16, FP16 = 0, 1
+W_GPTQ, W_NSEQ, W_AWQ = 0, 1, 2
+ZP_CONST, ZP_NSEQ, ZP_AWQ, ZP_GPTQ_V1 = 0, 1, 2, 3
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "oracle arrays must be C-contiguous"
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+
+# ---- bit helpers -------------------------------------------------------
+def f32_to_h16(x, dt=BF16):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty(x.shape, dtype=np.uint16)
+    lib().orc_f32_to_h16(_p(x), _p(y), ctypes.c_int64(x.size), _i(dt))
+    return y
+
+
+def h16_to_f32(x, dt=BF16):
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    y = np.empty(x.shape, dtype=np.float32)
+    lib().orc_h16_to_f32(_p(x), _p(y), ctypes.c_int64(x.size), _i(dt))
+    return y
+
+
+def f32_to_e4m3(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty(x.shape, dtype=np.uint8)
+    lib().orc_f32_to_e4m3(_p(x), _p(y), ctypes.c_int64(x.size))
+    return y
+
+
+def e4m3_to_f32(x):
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    y = np.empty(x.shape, dtype=np.float32)
+    lib().orc_e4m3_to_f32(_p(x), _p(y), ctypes.c_int64(x.size))
+    return y
+
+
+# ---- packers -----------------------------------------------------------
+def gptq_pack(q):
+    q = np.ascontiguousarray(q, dtype=np.int32)
+    K, N = q.shape
+    out = np.empty((K // 8, N), dtype=np.int32)
+    lib().orc_gptq_pack(_p(q), _p(out), _i(K), _i(N))
+    return out
+
+
+def pack_cols(q, awq_order=False):
+    q = np.ascontiguousarray(q, dtype=np.int32)
+    R, N = q.shape
+    out = np.empty((R, N // 8), dtype=np.int32)
+    lib().orc_pack_cols(_p(q), _p(out), _i(R), _i(N), _i(int(awq_order)))
+    return out
+
+
+def unpack_rows(p):
+    p = np.ascontiguousarray(p, dtype=np.int32)
+    K8, N = p.shape
+    out = np.empty((K8 * 8, N), dtype=np.int32)
+    lib().orc_unpack_rows(_p(p), _p(out), _i(K8 * 8), _i(N))
+    return out
+
+
+def unpack_cols(p, awq_order=False):
+    p = np.ascontiguousarray(p, dtype=np.int32)
+    R, N8 = p.shape
+    out = np.empty((R, N8 * 8), dtype=np.int32)
+    lib().orc_unpack_cols(_p(p), _p(out), _i(R), _i(N8 * 8), _i(int(awq_order)))
+    return out
+
+
+# ---- W4A16 -------------------------------------------------------------
+def _wshape(qw, layout):
+    if layout == W_GPTQ:
+        return qw.shape[0] * 8, qw.shape[1]
+    return qw.shape[0], qw.shape[1] * 8
+
+
+def w4a16_dequant(qw, scales, qz=None, G=128, layout=W_GPTQ, zp_mode=ZP_CONST, zp_const=8,
+                  dt=BF16, round_weight=False):
+    qw = np.ascontiguousarray(qw, dtype=np.int32)
+    K, N = _wshape(qw, layout)
+    W = np.empty((K, N), dtype=np.float32)
+    lib().orc_w4a16_dequant(_p(qw), _p(np.ascontiguousarray(scales)), _p(qz), _p(W), _i(K), _i(N),
+                            _i(G), _i(layout), _i(zp_mode), _i(zp_const), _i(dt),
+                            _i(int(round_weight)))
+    return W
+
+
+def w4a16_gemm(a, qw, scales, qz=None, bias=None, G=128, layout=W_GPTQ, zp_mode=ZP_CONST,
+               zp_const=8, dt=BF16, round_weight=False):
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    qw = np.ascontiguousarray(qw, dtype=np.int32)
+    K, N = _wshape(qw, layout)
+    M = a.shape[0]
+    assert a.shape[1] == K
+    c = np.empty((M, N), dtype=np.uint16)
+    lib().orc_w4a16_gemm(_p(a), _p(qw), _p(np.ascontiguousarray(scales)), _p(qz), _p(bias), _p(c),
+                         _i(M), _i(N), _i(K), _i(G), _i(layout), _i(zp_mode), _i(zp_const),
+                         _i(dt), _i(int(round_weight)))
+    return c
+
+
+def cpu_repack_gptq(qw):
+    qw = np.ascontiguousarray(qw, dtype=np.int32)
+    K, N = qw.shape[0] * 8, qw.shape[1]
+    out = np.empty((N // 16, K * 2), dtype=np.int32)
+    lib().orc_cpu_repack_gptq(_p(qw), _p(out), _i(K), _i(N))
+    return out
+
+
+def cpu_gemm_wna16(a, qwb, scales, zeros=None, bias=None, G=128, dt=BF16):
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    M, K = a.shape
+    N = qwb.shape[0] * 16
+    c = np.empty((M, N), dtype=np.uint16)
+    lib().orc_cpu_gemm_wna16(_p(a), _p(qwb), _p(np.ascontiguousarray(scales)), _p(zeros), _p(bias),
+                             _p(c), _i(M), _i(N), _i(K), _i(G), _i(dt))
+    return c
+
+
+def linear_h16(a, w, dt=BF16):
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    w = np.ascontiguousarray(w, dtype=np.uint16)
+    M, K = a.shape
+    N = w.shape[0]
+    c = np.empty((M, N), dtype=np.uint16)
+    lib().orc_linear_h16(_p(a), _p(w), _p(c), _i(M), _i(N), _i(K), _i(dt))
+    return c
+
+
+# ---- norms / rope / activation ----------------------------------------
+def rms_norm(x, w, eps, dt=BF16):
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    T, H = x.shape
+    out = np.empty_like(x)
+    lib().orc_rms_norm(_p(x), _p(w), _p(out), _i(T), _i(H), _f(eps), _i(dt))
+    return out
+
+
+def fused_add_rms_norm(x, residual, w, eps, dt=BF16):
+    x = np.array(x, dtype=np.uint16, copy=True, order="C")
+    r = np.array(residual, dtype=np.uint16, copy=True, order="C")
+    T, H = x.shape
+    lib().orc_fused_add_rms_norm(_p(x), _p(r), _p(w), _i(T), _i(H), _f(eps), _i(dt))
+    return x, r
+
+
+def rotary_embedding(positions, q, k, cache, head, is_neox, dt=BF16):
+    q = np.array(q, dtype=np.uint16, copy=True, order="C")
+    k = None if k is None else np.array(k, dtype=np.uint16, copy=True, order="C")
+    positions = np.ascontiguousarray(positions, dtype=np.int64)
+    T = positions.shape[0]
+    nh = q.size // T // head
+    nkv = 0 if k is None else k.size // T // head
+    rot = cache.shape[1]
+    lib().orc_rotary_embedding(_p(positions), _p(q), _p(k), _p(np.ascontiguousarray(cache)), _i(T),
+                               _i(nh), _i(nkv), _i(head), _i(rot), _i(int(is_neox)), _i(dt))
+    return q, k
+
+
+def silu_and_mul(x, dt=BF16):
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    T, d2 = x.shape
+    out = np.empty((T, d2 // 2), dtype=np.uint16)
+    lib().orc_silu_and_mul(_p(x), _p(out), _i(T), _i(d2 // 2), _i(dt))
+    return out
+
+
+# ---- KV cache / attention ---------------------------------------------
+def reshape_and_cache(key, value, kc, vc, slot_mapping, fp8=False, k_scale=1.0, v_scale=1.0,
+                      dt=BF16):
+    """kc [blocks, kvh, head/x, bs, x], vc [blocks, kvh, head, bs]; in place."""
+    key = np.ascontiguousarray(key, dtype=np.uint16)
+    value = np.ascontiguousarray(value, dtype=np.uint16)
+    T, kvh, head = key.shape
+    bs, x = kc.shape[3], kc.shape[4]
+    sm = np.ascontiguousarray(slot_mapping, dtype=np.int64)
+    lib().orc_reshape_and_cache(_p(key), _p(value), _p(kc), _p(vc), _p(sm), _i(T), _i(kvh),
+                                _i(head), _i(bs), _i(x), _i(int(fp8)), _f(k_scale), _f(v_scale),
+                                _i(dt))
+
+
+def paged_attention(q, kc, vc, block_tables, seq_lens, scale, alibi=None, fp8=False, k_scale=1.0,
+                    v_scale=1.0, dt=BF16):
+    q = np.ascontiguousarray(q, dtype=np.uint16)
+    S, H, D = q.shape
+    kvh, bs, x = kc.shape[1], kc.shape[3], kc.shape[4]
+    bt = np.ascontiguousarray(block_tables, dtype=np.int32)
+    sl = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    if alibi is not None:
+        alibi = np.ascontiguousarray(alibi, dtype=np.float32)
+    out = np.empty_like(q)
+    lib().orc_paged_attention(_p(q), _p(np.ascontiguousarray(kc)), _p(np.ascontiguousarray(vc)),
+                              _p(bt), _p(sl), _p(alibi), _p(out), _i(S), _i(H), _i(kvh), _i(D),
+                              _i(bs), _i(bt.shape[1]), _i(x), _i(int(fp8)), _f(scale),
+                              _f(k_scale), _f(v_scale), _i(dt))
+    return out
+
+
+def prefill_attention(q, k, v, scale, dt=BF16):
+    q = np.ascontiguousarray(q, dtype=np.uint16)
+    k = np.ascontiguousarray(k, dtype=np.uint16)
+    v = np.ascontiguousarray(v, dtype=np.uint16)
+    T, H, D = q.shape
+    kvh = k.shape[1]
+    out = np.empty_like(q)
+    lib().orc_prefill_attention(_p(q), _p(k), _p(v), _p(out), _i(T), _i(H), _i(kvh), _i(D),
+                                _f(scale), _i(dt))
+    return out
+
+
+# ---- sampler ------------------------------------------------------------
+def argmax_h16(logits, dt=BF16):
+    logits = np.ascontiguousarray(logits, dtype=np.uint16)
+    B, V = logits.shape
+    ids = np.empty((B,), dtype=np.int64)
+    lib().orc_argmax_h16(_p(logits), _p(ids), _i(B), _i(V), _i(dt))
+    return ids
+
+
+def argmax_f32(logits):
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    B, V = logits.shape
+    ids = np.empty((B,), dtype=np.int64)
+    lib().orc_argmax_f32(_p(logits), _p(ids), _i(B), _i(V))
+    return ids
+
+
+def apply_repetition_penalties(logits, prompt_mask, output_mask, penalties):
+    lg = np.array(logits, dtype=np.float32, copy=True, order="C")
+    B, V = lg.shape
+    pm = np.ascontiguousarray(prompt_mask, dtype=np.uint8)
+    om = np.ascontiguousarray(output_mask, dtype=np.uint8)
+    pen = np.ascontiguousarray(penalties, dtype=np.float32)
+    lib().orc_apply_repetition_penalties(_p(lg), _p(pm), _p(om), _p(pen), _i(B), _i(V))
+    return lg

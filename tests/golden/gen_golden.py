@@ -1,0 +1,479 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (authoring container only).
+
+Runs the reference's own pure-torch helpers (imported from /root/reference with
+stub modules for absent third-party packages) on seeded inputs and stores the
+inputs and expected outputs as small .npz files.  Only numeric data is stored.
+bf16/fp16 tensors are stored as their raw 16-bit patterns (uint16), fp8 as uint8.
+
+Where a reference helper cannot be imported on a GPU-less box (module-level
+skips or msgspec metaclasses), its arithmetic is restated here in torch and the
+file it follows is cited; those fixtures are marked restated=1.
+
+    python tests/golden/gen_golden.py
+"""
+import importlib
+import os
+import random
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+REF = os.environ.get("MI355Q_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+
+
+def imp(name):
+    while True:
+        try:
+            return importlib.import_module(name)
+        except ModuleNotFoundError as e:
+            if e.name is None or e.name.startswith(("vllm", "tests")):
+                raise
+            m = MagicMock(name=e.name)
+            m.__path__ = []
+            m.__spec__ = None
+            sys.modules[e.name] = m
+
+
+qu = imp("vllm.model_executor.layers.quantization.utils.quant_utils")
+st = imp("vllm.scalar_type").scalar_types
+ln = imp("vllm.ir.ops.layernorm")
+rope_base = imp("vllm.model_executor.layers.rotary_embedding.base")
+
+
+def bits16(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+
+
+def bits8(t):
+    return t.contiguous().view(torch.uint8).numpy().copy()
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------
+# G1: integer packers (quant_utils.py:537-577, 828-937)
+# --------------------------------------------------------------------------
+def gen_pack():
+    torch.manual_seed(0)
+    K, N = 64, 48
+    q = torch.randint(0, 16, (K, N), dtype=torch.int32)
+    z = torch.randint(0, 16, (K // 32, N), dtype=torch.int32)
+    save(
+        "pack",
+        q=q.numpy(),
+        z=z.numpy(),
+        gptq_pack=qu.gptq_pack(q, 4, K, N).numpy(),
+        pack_cols=qu.pack_cols(q, 4, K, N).numpy(),
+        awq_pack=qu.awq_pack(q, 4, K, N).numpy(),
+        z_pack_cols=qu.pack_cols(z, 4, K // 32, N).numpy(),
+        z_awq_pack=qu.awq_pack(z, 4, K // 32, N).numpy(),
+        pack_i32_dim0=qu.pack_quantized_values_into_int32(q, st.uint4, 0).numpy(),
+        pack_i32_dim1=qu.pack_quantized_values_into_int32(q, st.uint4, 1).numpy(),
+        unpack_cols=qu.unpack_cols(qu.pack_cols(q, 4, K, N), 4, K, N).numpy(),
+    )
+
+
+# --------------------------------------------------------------------------
+# G2: quantize_weights / gptq_quantize_weights (quant_utils.py:680-810)
+# --------------------------------------------------------------------------
+def gen_quantize():
+    out = {}
+    for tag, qt, G, zp in [
+        ("u4b8_g128", st.uint4b8, 128, False),
+        ("u4b8_g32", st.uint4b8, 32, False),
+        ("u4b8_gm1", st.uint4b8, -1, False),
+        ("u4_zp_g64", st.uint4, 64, True),
+        ("u8b128_g128", st.uint8b128, 128, False),
+    ]:
+        torch.manual_seed(0)
+        w = torch.randn(256, 32, dtype=torch.float32) / 10
+        w_ref, w_q, w_s, w_zp = qu.quantize_weights(w, qt, G, zp)
+        out[f"{tag}_w"] = w.numpy()
+        out[f"{tag}_w_ref"] = w_ref.numpy()
+        out[f"{tag}_w_q"] = w_q.numpy()
+        out[f"{tag}_w_s"] = w_s.numpy()
+        if w_zp is not None:
+            out[f"{tag}_w_zp"] = w_zp.numpy()
+    save("quantize", **out)
+
+
+# --------------------------------------------------------------------------
+# G3: W4A16 GEMM.  (a) inputs and reference of
+# tests/kernels/quantization/test_triton_w4a16.py:66-162 (restated: the module
+# skips itself at import on a non-ROCm platform); (b) GPTQ checkpoint route via
+# gptq_quantize_weights + gptq_pack with out = a @ w_ref (imported helpers).
+# --------------------------------------------------------------------------
+def _pack_n(w):  # test_triton_w4a16.py:33-43
+    K, N = w.shape
+    shifts = torch.arange(8, dtype=torch.int32) * 4
+    return torch.sum((w.view(K, N // 8, 8) & 0xF) << shifts, dim=2, dtype=torch.int32)
+
+
+def _unpack_n(p):  # test_triton_w4a16.py:46-52
+    K, N8 = p.shape
+    shifts = torch.arange(8, dtype=torch.int32) * 4
+    return ((p.unsqueeze(-1) >> shifts) & 0xF).reshape(K, N8 * 8)
+
+
+def _w4a16_reference(a, b_packed, scales, G, qzeros, zp_bias):  # :66-107
+    M, K = a.shape
+    w = _unpack_n(b_packed)
+    N = w.shape[1]
+    if qzeros is None:
+        z = torch.full((K, N), zp_bias, dtype=torch.int32)
+    else:
+        z = _unpack_n(qzeros).repeat_interleave(G, dim=0)
+    s = scales.repeat_interleave(G, dim=0).to(torch.float32)
+    w_fp = (w - z).to(torch.float32) * s
+    return (a.to(torch.float32) @ w_fp).to(a.dtype)
+
+
+def gen_w4a16():
+    out = {}
+    cases = [
+        (1, 256, 256, 32, False),
+        (17, 256, 512, 32, False),
+        (32, 512, 256, 64, False),
+        (33, 512, 512, 128, False),
+        (64, 1024, 256, 256, False),
+        (128, 256, 1024, 32, True),
+        (64, 512, 512, 64, True),
+    ]
+    names = []
+    for dtype, dn in [(torch.bfloat16, "bf16"), (torch.float16, "fp16")]:
+        for M, K, N, G, has_zp in cases:
+            if dn == "fp16" and M > 17:
+                continue
+            torch.manual_seed(0)
+            a = (0.25 * torch.randn((M, K), dtype=torch.float32)).to(dtype)
+            w = torch.randint(0, 16, (K, N), dtype=torch.int32)
+            bp = _pack_n(w)
+            s = (0.05 * torch.rand((K // G, N), dtype=torch.float32)).to(dtype)
+            qz = None
+            if has_zp:
+                qz = _pack_n(torch.randint(0, 16, (K // G, N), dtype=torch.int32))
+            ref = _w4a16_reference(a, bp, s, G, qz, 8)
+            tag = f"{dn}_m{M}_k{K}_n{N}_g{G}_zp{int(has_zp)}"
+            names.append(tag)
+            out[tag + "_a"] = bits16(a)
+            out[tag + "_b"] = bp.numpy()
+            out[tag + "_s"] = bits16(s)
+            if qz is not None:
+                out[tag + "_z"] = qz.numpy()
+            out[tag + "_ref"] = bits16(ref)
+    out["names"] = np.array(names)
+    save("w4a16_triton_cases", **out)
+
+    # GPTQ checkpoint route (imported reference quantiser + packer).
+    out = {}
+    names = []
+    for M, K, N, G in [(1, 256, 128, 128), (5, 512, 64, 32), (16, 256, 64, -1)]:
+        torch.manual_seed(0)
+        w = torch.randn(K, N, dtype=torch.float32) / 10
+        w_ref, w_q, w_s, g_idx, _ = qu.gptq_quantize_weights(
+            w.to(torch.bfloat16), st.uint4b8, G if G != -1 else K, False
+        )
+        qweight = qu.gptq_pack(w_q, 4, K, N)
+        a = (0.25 * torch.randn((M, K), dtype=torch.float32)).to(torch.bfloat16)
+        ref = (a.float() @ w_ref.float()).to(torch.bfloat16)
+        tag = f"m{M}_k{K}_n{N}_g{G}"
+        names.append(tag)
+        out[tag + "_a"] = bits16(a)
+        out[tag + "_qweight"] = qweight.numpy()
+        out[tag + "_scales"] = bits16(w_s.to(torch.bfloat16))
+        out[tag + "_w_ref"] = bits16(w_ref)
+        out[tag + "_ref"] = bits16(ref)
+    out["names"] = np.array(names)
+    save("w4a16_gptq_route", **out)
+
+
+# --------------------------------------------------------------------------
+# G4: AWQ.  quantize_weights(uint4, zero points) + awq_pack (imported); the
+# dequantised weight expected from the packed tensors is w_ref.  The AWQ
+# dequantize reference of tests/kernels/quantization/test_awq_triton.py:27-74
+# (reverse order [0,4,1,5,2,6,3,7]) is restated to produce `deq`.
+# --------------------------------------------------------------------------
+def _awq_dequantize_torch(qweight, scales, qzeros, G):  # test_awq_triton.py:27-74
+    rev = [0, 4, 1, 5, 2, 6, 3, 7]
+    shifts = torch.arange(0, 32, 4)
+
+    def unpack(t):
+        u = torch.bitwise_right_shift(t[:, :, None], shifts[None, None, :]).to(torch.int8)
+        u = u.view(t.shape[0], -1)
+        order = torch.arange(u.shape[-1], dtype=torch.int32).view(-1, 8)[:, rev].reshape(-1)
+        return u[:, order] & 0xF
+
+    iw = unpack(qweight)
+    z = unpack(qzeros).repeat_interleave(G, dim=0)
+    s = scales.repeat_interleave(G, dim=0)
+    return (iw - z) * s
+
+
+def gen_awq():
+    out = {}
+    names = []
+    for M, K, N, G in [(1, 256, 128, 128), (7, 256, 64, 32), (16, 512, 64, 64)]:
+        torch.manual_seed(0)
+        w = torch.randn(K, N, dtype=torch.float32) / 10
+        w_ref, w_q, w_s, w_zp = qu.quantize_weights(w.to(torch.float16), st.uint4, G, True)
+        qweight = qu.awq_pack(w_q, 4, K, N)
+        qzeros = qu.awq_pack(w_zp, 4, K // G, N)
+        deq = _awq_dequantize_torch(qweight, w_s, qzeros, G)
+        assert torch.equal(deq.to(torch.float16), w_ref.to(torch.float16))
+        a = (0.25 * torch.randn((M, K), dtype=torch.float32)).to(torch.float16)
+        ref = (a.float() @ w_ref.float()).to(torch.float16)
+        tag = f"m{M}_k{K}_n{N}_g{G}"
+        names.append(tag)
+        out[tag + "_a"] = bits16(a)
+        out[tag + "_qweight"] = qweight.numpy()
+        out[tag + "_qzeros"] = qzeros.numpy()
+        out[tag + "_scales"] = bits16(w_s.to(torch.float16))
+        out[tag + "_deq"] = bits16(deq.to(torch.float16))
+        out[tag + "_ref"] = bits16(ref)
+    out["names"] = np.array(names)
+    save("awq", **out)
+
+
+# --------------------------------------------------------------------------
+# G5: RMSNorm.  native IR impl (vllm/ir/ops/layernorm.py:9-62, imported) and the
+# kernel-order fused variant (csrc/libtorch_stable/layernorm_kernels.cu:133-172:
+# residual sum rounded to the activation dtype before the variance; restated).
+# --------------------------------------------------------------------------
+def _unwrap(op):
+    for attr in ("impls",):
+        if hasattr(op, attr):
+            return getattr(op, attr)["native"].impl_fn
+    return op
+
+
+def _native(op):
+    impls = getattr(op, "impls", None)
+    if impls is not None and "native" in impls:
+        impl = impls["native"]
+        for a in ("impl_fn", "fn", "func"):
+            if hasattr(impl, a):
+                return getattr(impl, a)
+        return impl
+    return op
+
+
+def gen_rmsnorm():
+    rms = _native(ln.rms_norm)
+    fused = _native(ln.fused_add_rms_norm)
+    out = {}
+    names = []
+    for T, H in [(7, 768), (3, 4096), (2, 5125), (1, 8192)]:
+        torch.manual_seed(0)
+        x = torch.randn(T, H).to(torch.bfloat16)
+        r = torch.randn(T, H).to(torch.bfloat16)
+        w = torch.randn(H).to(torch.bfloat16)
+        eps = 1e-5
+        y = rms(x, w, eps)
+        y2, r2 = fused(x.clone(), r.clone(), w, eps)
+        # kernel-order: z = bf16(x + r); var from z; out = bf16(z * rs * w)
+        z = (x.float() + r.float()).to(torch.bfloat16)
+        var = z.float().pow(2).mean(dim=-1, keepdim=True)
+        yk = (z.float() * torch.rsqrt(var + eps) * w.float()).to(torch.bfloat16)
+        # single-rounding rms_norm of the CUDA kernel (layernorm_kernels.cu:89-97)
+        var1 = x.float().pow(2).mean(dim=-1, keepdim=True)
+        y1 = (x.float() * torch.rsqrt(var1 + eps) * w.float()).to(torch.bfloat16)
+        tag = f"t{T}_h{H}"
+        names.append(tag)
+        out[tag + "_x"] = bits16(x)
+        out[tag + "_r"] = bits16(r)
+        out[tag + "_w"] = bits16(w)
+        out[tag + "_native"] = bits16(y)
+        out[tag + "_kernel"] = bits16(y1)
+        out[tag + "_fused_native"] = bits16(y2)
+        out[tag + "_fused_native_res"] = bits16(r2)
+        out[tag + "_fused_kernel"] = bits16(yk)
+        out[tag + "_fused_kernel_res"] = bits16(z)
+    out["names"] = np.array(names)
+    save("rmsnorm", **out)
+
+
+# --------------------------------------------------------------------------
+# G6: RoPE.  RotaryEmbedding.forward_static (rotary_embedding/base.py:160-201,
+# imported) on a cos/sin cache built as base.py:80-103, cast to bf16.
+# --------------------------------------------------------------------------
+def gen_rope():
+    out = {}
+    names = []
+    for head, rot, neox, nh, nkv in [
+        (128, 128, True, 8, 2),
+        (64, 64, False, 4, 4),
+        (128, 32, True, 4, 1),
+        (64, 32, False, 2, 2),
+    ]:
+        torch.manual_seed(0)
+        T, max_pos, base = 5, 64, 10000.0
+        inv_freq = 1.0 / (base ** (torch.arange(0, rot, 2, dtype=torch.float) / rot))
+        t = torch.arange(max_pos, dtype=torch.float)
+        freqs = torch.einsum("i,j -> ij", t, inv_freq)
+        cache = torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(torch.bfloat16)
+        pos = torch.randint(0, max_pos, (T,), dtype=torch.int64)
+        q = torch.randn(T, nh * head).to(torch.bfloat16)
+        k = torch.randn(T, nkv * head).to(torch.bfloat16)
+        qo, ko = rope_base.RotaryEmbedding.forward_static(pos, q.clone(), k.clone(), head, rot, cache, neox)
+        tag = f"h{head}_r{rot}_neox{int(neox)}"
+        names.append(tag)
+        out[tag + "_pos"] = pos.numpy()
+        out[tag + "_q"] = bits16(q)
+        out[tag + "_k"] = bits16(k)
+        out[tag + "_cache"] = bits16(cache)
+        out[tag + "_qo"] = bits16(qo)
+        out[tag + "_ko"] = bits16(ko)
+        out[tag + "_meta"] = np.array([head, rot, int(neox), nh, nkv])
+    out["names"] = np.array(names)
+    save("rope", **out)
+
+
+# --------------------------------------------------------------------------
+# G7: paged attention (decode).  Reference restated from
+# tests/kernels/attention/test_attention.py:42-109 (module import needs the
+# compiled _C_cuda_utils); KV layout of vllm/v1/attention/ops/paged_attn.py:16-29.
+# fp8 KV: stored = float8_e4m3fn(x / scale), read = float(stored) * scale
+# (kv_cache.py:95-151, csrc/quantization/w8a8/fp8/amd/quant_utils.cuh:29-49).
+# --------------------------------------------------------------------------
+def _ref_paged(q, kc, vc, block_tables, seq_lens, scale, alibi):
+    S, H, D = q.shape
+    KVH = vc.shape[1]
+    bs = vc.shape[3]
+    rep = H // KVH
+    out = torch.empty_like(q)
+    for i in range(S):
+        L = int(seq_lens[i])
+        ks, vs = [], []
+        for j in range(L):
+            b = int(block_tables[i, j // bs])
+            o = j % bs
+            ks.append(kc[b, :, :, o, :].reshape(KVH, D))
+            vs.append(vc[b, :, :, o])
+        keys = torch.stack(ks, 0)
+        vals = torch.stack(vs, 0)
+        if rep > 1:
+            keys = torch.repeat_interleave(keys, rep, dim=1)
+            vals = torch.repeat_interleave(vals, rep, dim=1)
+        w = scale * torch.einsum("qhd,khd->hqk", q[i : i + 1], keys).float()
+        if alibi is not None:
+            bias = (torch.arange(L).int() - L + 1).float()
+            w = w + alibi.view(-1, 1, 1) * bias.view(1, 1, -1)
+        w = torch.softmax(w, dim=-1).to(vals.dtype)
+        out[i] = torch.einsum("hqk,khd->qhd", w, vals).view(H, D)
+    return out
+
+
+def gen_paged_attn():
+    out = {}
+    names = []
+    for tag, H, KVH, D, bs, lens, kvdt, use_alibi, nblk in [
+        ("bf16_h8_kv2_d128_b16", 8, 2, 128, 16, [1, 17, 260], "auto", False, 24),
+        ("bf16_h4_kv4_d64_b32", 4, 4, 64, 32, [33, 257], "auto", False, 12),
+        ("fp8_h8_kv2_d128_b16", 8, 2, 128, 16, [5, 290], "fp8", False, 24),
+        ("fp8_h16_kv2_d128_b32", 16, 2, 128, 32, [64, 520], "fp8", False, 20),
+        ("bf16_alibi_h8_kv2_d128_b16", 8, 2, 128, 16, [40, 260], "auto", True, 20),
+    ]:
+        torch.manual_seed(0)
+        random.seed(0)
+        S = len(lens)
+        scale = float(1.0 / (D**0.5))
+        q = torch.empty(S, H, D).uniform_(-scale, scale).to(torch.bfloat16)
+        x = 16 if kvdt == "fp8" else 8
+        kc = torch.empty(nblk, KVH, D // x, bs, x).uniform_(-scale, scale)
+        vc = torch.empty(nblk, KVH, D, bs).uniform_(-scale, scale)
+        max_blocks = (max(lens) + bs - 1) // bs
+        bt = torch.tensor(
+            [[random.randint(0, nblk - 1) for _ in range(max_blocks)] for _ in range(S)],
+            dtype=torch.int32,
+        )
+        sl = torch.tensor(lens, dtype=torch.int32)
+        alibi = torch.randn(H, dtype=torch.float) if use_alibi else None
+        if kvdt == "fp8":
+            k_scale, v_scale = 0.5 / 16, 0.25 / 16
+            kq = (kc / k_scale).to(torch.float8_e4m3fn)
+            vq = (vc / v_scale).to(torch.float8_e4m3fn)
+            # dequantise as convert_fp8 does, to the activation dtype
+            kd = (kq.float() * k_scale).to(torch.bfloat16)
+            vd = (vq.float() * v_scale).to(torch.bfloat16)
+            # the reference reads K as [blk, kvh, D/x', bs, x'] with x' of bf16 (8)
+            kd8 = kd.permute(0, 1, 3, 2, 4).reshape(nblk, KVH, bs, D)
+            kd8 = kd8.reshape(nblk, KVH, bs, D // 8, 8).permute(0, 1, 3, 2, 4).contiguous()
+            ref = _ref_paged(q, kd8, vd, bt, sl, scale, alibi)
+            out[tag + "_kc"] = bits8(kq)
+            out[tag + "_vc"] = bits8(vq)
+            out[tag + "_kv_scale"] = np.array([k_scale, v_scale], dtype=np.float32)
+        else:
+            kcb = kc.to(torch.bfloat16)
+            vcb = vc.to(torch.bfloat16)
+            ref = _ref_paged(q, kcb, vcb, bt, sl, scale, alibi)
+            out[tag + "_kc"] = bits16(kcb)
+            out[tag + "_vc"] = bits16(vcb)
+        names.append(tag)
+        out[tag + "_q"] = bits16(q)
+        out[tag + "_bt"] = bt.numpy()
+        out[tag + "_sl"] = sl.numpy()
+        out[tag + "_ref"] = bits16(ref)
+        out[tag + "_meta"] = np.array([H, KVH, D, bs, int(kvdt == "fp8")])
+        out[tag + "_scale"] = np.array([scale], dtype=np.float32)
+        if alibi is not None:
+            out[tag + "_alibi"] = alibi.numpy()
+    out["names"] = np.array(names)
+    save("paged_attn", **out)
+
+
+# --------------------------------------------------------------------------
+# G9: sampler inner loop.  Greedy = logits.float().argmax(-1)
+# (vllm/v1/sample/sampler.py:96,240-241; restated: the module derives from
+# msgspec.Struct and cannot be imported with a stub) and repetition penalties
+# (vllm/_custom_ops.py:309-322, imported below when possible).
+# --------------------------------------------------------------------------
+def gen_sampler():
+    torch.manual_seed(0)
+    B, V = 4, 1000
+    logits = torch.randn(B, V).to(torch.bfloat16)
+    logits[1, 17] = logits[1].max() + 1
+    logits[1, 900] = logits[1, 17]  # tie: first index wins
+    logits[2, :] = 0.5  # all equal -> 0
+    ids = logits.float().argmax(dim=-1)
+    prompt_mask = torch.rand(B, V) < 0.1
+    output_mask = torch.rand(B, V) < 0.1
+    pen = torch.tensor([1.0, 1.2, 2.0, 0.8])
+    lg = logits.float().clone()
+    try:
+        ops = imp("vllm._custom_ops")
+        ops.apply_repetition_penalties_torch(lg, prompt_mask, output_mask, pen)
+        restated = 0
+    except Exception:
+        p = torch.where(prompt_mask | output_mask, pen.unsqueeze(1).repeat(1, V), 1.0)
+        lg *= torch.where(lg > 0, 1.0 / p, p)
+        restated = 1
+    save(
+        "sampler",
+        logits=bits16(logits),
+        argmax=ids.numpy(),
+        prompt_mask=prompt_mask.numpy(),
+        output_mask=output_mask.numpy(),
+        penalties=pen.numpy(),
+        penalized=lg.numpy(),
+        restated=np.array([restated]),
+    )
+
+
+if __name__ == "__main__":
+    gen_pack()
+    gen_quantize()
+    gen_w4a16()
+    gen_awq()
+    gen_rmsnorm()
+    gen_rope()
+    gen_paged_attn()
+    gen_sampler()
