@@ -1,0 +1,239 @@
+/*
+ * mi355q.h -- C ABI of libmi355q.so, the MI355X (gfx950) quantized-decode
+ * kernel library.  Plain pointers and sizes only; no torch types.
+ *
+ * Every device pointer is memory owned by the caller (torch's caching
+ * allocator in the vLLM integration).  No entry point allocates or frees device
+ * memory, synchronises the host, or touches any stream other than the one
+ * passed in, so all of them can be captured into a HIP graph.
+ *
+ * Return value: 0 on success, a negative MI355Q_E* code otherwise;
+ * mi355q_last_error() returns a thread-local message for the last failure
+ * (the Python side turns it into RuntimeError, as TORCH_CHECK does in the
+ * reference).
+ *
+ * "Replaces" comments cite the reference interface (file:line, relative to the
+ * vLLM fork's tree) that each entry point stands in for.
+ */
+#ifndef MI355Q_H
+#define MI355Q_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mi355q_stream_t; /* hipStream_t */
+
+enum {
+  MI355Q_OK = 0,
+  MI355Q_EINVAL = -1,   /* bad shape / alignment / enum */
+  MI355Q_ENOSPACE = -2, /* workspace too small */
+  MI355Q_EHIP = -3      /* HIP runtime error at launch */
+};
+
+enum { MI355Q_BF16 = 0, MI355Q_FP16 = 1, MI355Q_FP32 = 2 };
+
+/* checkpoint layouts of 4-bit weights accepted by the repack */
+enum {
+  MI355Q_W_GPTQ = 0, /* int32 [K/8, N], 8 consecutive k per word (auto_gptq.py:381-445) */
+  MI355Q_W_NSEQ = 1, /* int32 [K, N/8], 8 consecutive n per word (triton_w4a16.py:368-389) */
+  MI355Q_W_AWQ = 2   /* int32 [K, N/8], AWQ nibble order (auto_awq.py:478-515) */
+};
+
+/* zero-point conventions accepted by the repack */
+enum {
+  MI355Q_ZP_CONST = 0,  /* symmetric uint4b8: z = 8, qzeros ignored (triton_w4a16.py:440-444) */
+  MI355Q_ZP_NSEQ = 1,   /* int32 [K/G, N/8] sequential nibbles, value z */
+  MI355Q_ZP_AWQ = 2,    /* int32 [K/G, N/8] AWQ nibble order, value z */
+  MI355Q_ZP_GPTQ_V1 = 3 /* int32 [K/G, N/8] sequential, stores z-1 (q_gemm.cu:202) */
+};
+
+const char* mi355q_last_error(void);
+int mi355q_version(void);
+
+/* ------------------------------------------------------------------ */
+/* W4A16 dequant-GEMM                                                  */
+/* ------------------------------------------------------------------ */
+
+/*
+ * Load-time repack of a 4-bit checkpoint tensor into the kernel's tiled layout
+ * (1 KiB tiles of 64 output channels x 32 input channels).
+ * Replaces MPLinearKernel.process_weights_after_loading
+ * (mixed_precision/MPLinearKernel.py:56-58; triton_w4a16.py:338-426;
+ * exllama.py:60-136 + gptq_shuffle q_gemm.cu:1857-1868).
+ *   qweight : device, layout per src_layout
+ *   qzeros  : device or NULL (required unless zp_mode == MI355Q_ZP_CONST)
+ *   packed  : device out, K*N/2 bytes
+ *   zc      : device out, (K/G)*N 16-bit values of (bias + z) in act_dtype, or
+ *             NULL when zp_mode == MI355Q_ZP_CONST
+ * Requires K % 32 == 0, N % 64 == 0, G % 32 == 0 and K % G == 0 (G <= 0 means K).
+ */
+int mi355q_w4a16_repack(const int32_t* qweight, const int32_t* qzeros, void* packed, void* zc,
+                        int K, int N, int G, int src_layout, int zp_mode, int act_dtype,
+                        mi355q_stream_t stream);
+/* Same arithmetic on host memory (used by load paths that repack before upload
+ * and by the CPU-only tests). */
+int mi355q_w4a16_repack_host(const int32_t* qweight, const int32_t* qzeros, void* packed, void* zc,
+                             int K, int N, int G, int src_layout, int zp_mode, int act_dtype);
+/* Inverse of the weight repack: packed tiles -> int32 [K, N] values in [0,16). */
+int mi355q_w4a16_unpack_host(const void* packed, int32_t* q, int K, int N);
+
+size_t mi355q_w4a16_packed_bytes(int K, int N);
+size_t mi355q_w4a16_workspace_bytes(int M, int N, int K, int G);
+
+/*
+ * C[M,N] = A[M,K] * ((q - z) * s)  (+ bias), fp32 accumulation, one rounding.
+ * Replaces ops.gptq_gemm (vllm/_custom_ops.py:558-577; q_gemm.cu:1827-1855),
+ * ops.awq_gemm (:525-536; awq/gemm_kernels.cu:472-536) and triton_w4a16_gemm
+ * (mixed_precision/triton_w4a16.py:164-270).
+ *   a      : [M, K] act_dtype, row stride lda elements (lda % 8 == 0)
+ *   packed : output of mi355q_w4a16_repack
+ *   scales : [K/G, N] act_dtype (checkpoint layout, not repacked)
+ *   zc     : from the repack, or NULL for symmetric uint4b8
+ *   bias   : [N] act_dtype or NULL
+ *   c      : [M, N] act_dtype, contiguous
+ *   workspace : >= mi355q_w4a16_workspace_bytes(M,N,K,G) bytes (split-K partials)
+ *   split_k   : 0 = choose automatically
+ */
+int mi355q_w4a16_gemm(const void* a, int lda, const void* packed, const void* scales,
+                      const void* zc, const void* bias, void* c, int M, int N, int K, int G,
+                      int act_dtype, void* workspace, size_t workspace_bytes, int split_k,
+                      mi355q_stream_t stream);
+
+/*
+ * Same GEMM with A formed on the fly as silu(x[:, :K]) * x[:, K:] from
+ * x [M, 2K] (the gate_up projection output), i.e. SiluAndMul fused into the
+ * down projection.  Replaces torch.ops._C.silu_and_mul
+ * (activation_kernels.cu:98-155) + the GEMM above.
+ */
+int mi355q_w4a16_gemm_silu_mul(const void* x, int ldx, const void* packed, const void* scales,
+                               const void* zc, const void* bias, void* c, int M, int N, int K,
+                               int G, int act_dtype, void* workspace, size_t workspace_bytes,
+                               int split_k, mi355q_stream_t stream);
+
+/* W[K,N] (act_dtype) = (q - z) * s.  Replaces ops.awq_dequantize
+ * (vllm/_custom_ops.py:491-505; awq/gemm_kernels.cu:414-464). */
+int mi355q_w4a16_dequantize(const void* packed, const void* scales, const void* zc, void* w,
+                            int K, int N, int G, int act_dtype, mi355q_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* Unquantized skinny linear (lm_head, bf16 decode comparator)         */
+/* ------------------------------------------------------------------ */
+/* C[M,N] = A[M,K] * W[N,K]^T (+ bias); M <= 16 per pass.  Replaces
+ * ops.wvSplitK / ops.LLMM1 (vllm/_custom_ops.py:2161-2213;
+ * csrc/rocm/skinny_gemms.cu) as dispatched by layers/utils.py:116-186. */
+int mi355q_linear_skinny(const void* a, int lda, const void* w, const void* bias, void* c, int M,
+                         int N, int K, int act_dtype, mi355q_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* Norms, RoPE, activation                                             */
+/* ------------------------------------------------------------------ */
+/* Replaces torch.ops._C.rms_norm (layernorm_kernels.cu:14-100,221-293). */
+int mi355q_rms_norm(void* out, const void* input, int64_t input_stride, const void* weight,
+                    float epsilon, int num_tokens, int hidden, int dtype, mi355q_stream_t stream);
+/* In place on input and residual.  Replaces torch.ops._C.fused_add_rms_norm
+ * (layernorm_kernels.cu:106-217,314-373). */
+int mi355q_fused_add_rms_norm(void* input, int64_t input_stride, void* residual,
+                              const void* weight, float epsilon, int num_tokens, int hidden,
+                              int dtype, mi355q_stream_t stream);
+/*
+ * residual[t] = round(residual[t] + sum_s partial[s][t] (+ bias));
+ * out[t] = round(residual[t] * rsqrt(mean(residual[t]^2) + eps) * weight).
+ * The split-K partials of the preceding row-parallel GEMM are consumed here
+ * instead of being reduced by a kernel of their own (no reference counterpart;
+ * same arithmetic as gemm -> fused_add_rms_norm).
+ */
+int mi355q_splitk_add_rms_norm(void* out, void* residual, const float* partial, int splits,
+                               const void* bias, const void* weight, float epsilon,
+                               int num_tokens, int hidden, int dtype, mi355q_stream_t stream);
+/* In place on query/key.  positions int64 [T].  Replaces ops.rotary_embedding
+ * (vllm/_custom_ops.py:201-225; pos_encoding_kernels.cu:76-201). */
+int mi355q_rotary_embedding(const int64_t* positions, void* query, int64_t query_stride,
+                            void* key, int64_t key_stride, int head_size, int num_heads,
+                            int num_kv_heads, const void* cos_sin_cache, int rot_dim,
+                            int cache_dtype, int is_neox, int num_tokens, int dtype,
+                            mi355q_stream_t stream);
+/* out[T,d] = silu(x[T,:d]) * x[T,d:].  Replaces torch.ops._C.silu_and_mul. */
+int mi355q_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dtype,
+                        mi355q_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* KV cache + paged attention (ROCM_ATTN layout)                       */
+/* K cache [blocks, kv_heads, head/x, block_size, x], x = 16 / elem    */
+/* V cache [blocks, kv_heads, head, block_size]                        */
+/* ------------------------------------------------------------------ */
+/* kv_fp8 = 0: cache holds `dtype` elements; 1: OCP e4m3fn bytes of value/scale.
+ * k_scale/v_scale: DEVICE fp32 scalars (read through the pointer, as the
+ * reference does).  slot_mapping int64 [T], negative = skip.
+ * Replaces ops.reshape_and_cache (vllm/_custom_ops.py:2592-2611;
+ * cache_kernels.cu:254-312,749-780). */
+int mi355q_reshape_and_cache(const void* key, const void* value, int64_t key_stride,
+                             int64_t value_stride, void* key_cache, void* value_cache,
+                             const int64_t* slot_mapping, int num_tokens, int num_kv_heads,
+                             int head_size, int block_size, int64_t block_stride, int dtype,
+                             int kv_fp8, const float* k_scale, const float* v_scale,
+                             mi355q_stream_t stream);
+/* dst = fp8 -> dtype or dtype -> fp8 element-wise with scale.  Replaces
+ * ops.convert_fp8 (vllm/_custom_ops.py:2908; cache_kernels.cu:1003-1060). */
+int mi355q_convert_fp8(void* dst, const void* src, int64_t n, float scale, int dtype,
+                       int to_fp8, mi355q_stream_t stream);
+
+#define MI355Q_PA_PARTITION 256
+/*
+ * Decode-only paged attention (rows whose query length != 1 are skipped when
+ * query_start_loc != NULL).  Replaces ops.paged_attention_rocm
+ * (vllm/_custom_ops.py:120-163; csrc/rocm/attention.cu:3652-3712): same
+ * argument meaning; exp_sums/max_logits [S, H, P] fp32 and tmp_out [S, H, P, D]
+ * are caller-allocated scratch with P = ceil(max_seq_len / 256).
+ */
+int mi355q_paged_attention(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                           const void* query, int64_t q_stride, const void* key_cache,
+                           const void* value_cache, int64_t kv_block_stride,
+                           int64_t kv_head_stride, int num_seqs, int num_heads,
+                           int num_kv_heads, int head_size, float scale,
+                           const int32_t* block_tables, int max_blocks_per_seq,
+                           const int32_t* seq_lens, const int32_t* query_start_loc,
+                           int block_size, int max_seq_len, const float* alibi_slopes,
+                           int dtype, int kv_fp8, const float* k_scale, const float* v_scale,
+                           mi355q_stream_t stream);
+
+/*
+ * Attention for rows with query length >= 1 (prompt rows), reading K/V back from
+ * the paged cache after reshape_and_cache has written the new tokens: query row
+ * j of sequence s attends cache positions [0, seq_lens[s] - query_len[s] + j].
+ * query [T, H, D]; query_start_loc int32 [S+1] (required); scratch buffers are
+ * indexed by query row: exp_sums/max_logits [T, H, P], tmp_out [T, H, P, D].
+ * Stands in for the prompt rows that the reference hands to context_attention_fwd
+ * (vllm/v1/attention/ops/chunked_prefill_paged_decode.py:303-326,
+ * ops/prefix_prefill.py).
+ */
+int mi355q_paged_prefill_attention(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+    int64_t q_stride, const void* key_cache, const void* value_cache, int64_t kv_block_stride,
+    int64_t kv_head_stride, int num_seqs, int num_heads, int num_kv_heads, int head_size,
+    float scale, const int32_t* block_tables, int max_blocks_per_seq, const int32_t* seq_lens,
+    const int32_t* query_start_loc, int max_query_len, int block_size, int max_seq_len,
+    const float* alibi_slopes, int dtype, int kv_fp8, const float* k_scale, const float* v_scale,
+    mi355q_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* Sampler inner loop                                                  */
+/* ------------------------------------------------------------------ */
+/* ids[b] = first index of max(float(logits[b, :])).  Replaces
+ * logits.float().argmax(-1) (vllm/v1/sample/sampler.py:96,240-241). */
+int mi355q_argmax(const void* logits, int64_t row_stride, int64_t* ids, int num_rows, int vocab,
+                  int dtype, mi355q_stream_t stream);
+/* In place; masks are bool (1 byte) [B, V]; penalties [B] in logits dtype.
+ * Replaces ops.apply_repetition_penalties_ (vllm/_custom_ops.py:325-333;
+ * sampler.cu:13-49,618-659). */
+int mi355q_apply_repetition_penalties(void* logits, const uint8_t* prompt_mask,
+                                      const uint8_t* output_mask, const void* penalties,
+                                      int num_seqs, int vocab, int dtype, mi355q_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355Q_H */

@@ -1,0 +1,456 @@
+"""Parity of the HIP kernels (called through the C ABI via mi355q.ops) against the CPU
+oracle and the golden fixtures.  Needs a real MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from mi355q import _lib, ops
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TDT = {orc.BF16: torch.bfloat16, orc.FP16: torch.float16}
+
+
+def to_dev(bits, dt=orc.BF16):
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(TDT[dt]).to(DEV)
+
+
+def to_bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def f32(bits, dt=orc.BF16):
+    return orc.h16_to_f32(bits, dt)
+
+
+def i32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(DEV)
+
+
+# ---------------------------------------------------------------------------
+# W4A16
+# ---------------------------------------------------------------------------
+def test_w4a16_golden_triton_cases(golden):
+    """tests/kernels/quantization/test_triton_w4a16.py:112-162 inputs; rtol=atol=1e-2 (:162)."""
+    g = golden("w4a16_triton_cases")
+    for tag in g["names"]:
+        tag = str(tag)
+        N = int(tag.split("_n")[1].split("_")[0])
+        if N % 64:
+            continue
+        dt = orc.BF16 if tag.startswith("bf16") else orc.FP16
+        G = int(tag.split("_g")[1].split("_")[0])
+        has_zp = tag.endswith("zp1")
+        w = ops.w4a16_repack(i32(g[tag + "_b"]), to_dev(g[tag + "_s"], dt), i32(g[tag + "_z"]) if has_zp else None,
+                             G, _lib.W_NSEQ, _lib.ZP_NSEQ if has_zp else _lib.ZP_CONST)
+        out = ops.w4a16_gemm(to_dev(g[tag + "_a"], dt), w)
+        np.testing.assert_allclose(f32(to_bits(out), dt), f32(g[tag + "_ref"], dt), rtol=1e-2, atol=1e-2, err_msg=tag)
+
+
+def test_w4a16_golden_gptq_and_awq_routes(golden):
+    g = golden("w4a16_gptq_route")
+    for tag in g["names"]:
+        tag = str(tag)
+        G = int(tag.split("_g")[1])
+        w = ops.w4a16_repack(i32(g[tag + "_qweight"]), to_dev(g[tag + "_scales"]), None, G)
+        out = ops.w4a16_gemm(to_dev(g[tag + "_a"]), w)
+        np.testing.assert_allclose(f32(to_bits(out)), f32(g[tag + "_ref"]), rtol=1e-2, atol=1e-2, err_msg=tag)
+        deq = ops.w4a16_dequantize(w)
+        assert np.array_equal(to_bits(deq), g[tag + "_w_ref"]), tag
+    g = golden("awq")
+    for tag in g["names"]:
+        tag = str(tag)
+        G = int(tag.split("_g")[1])
+        w = ops.w4a16_repack(i32(g[tag + "_qweight"]), to_dev(g[tag + "_scales"], orc.FP16), i32(g[tag + "_qzeros"]),
+                             G, _lib.W_AWQ, _lib.ZP_AWQ)
+        assert np.array_equal(to_bits(ops.w4a16_dequantize(w)), g[tag + "_deq"]), tag
+        out = ops.w4a16_gemm(to_dev(g[tag + "_a"], orc.FP16), w)
+        np.testing.assert_allclose(f32(to_bits(out), orc.FP16), f32(g[tag + "_ref"], orc.FP16), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,K,N,G,split", [(1, 4096, 4096, 128, 0), (1, 4096, 4096, 128, 1), (3, 1024, 1280, 128, 0),
+                                           (8, 3584, 512, 128, 0), (16, 512, 256, 32, 3), (17, 256, 128, 64, 0),
+                                           (40, 512, 192, -1, 2), (5, 1024, 64, 128, 8)])
+def test_w4a16_vs_oracle(M, K, N, G, split):
+    rng = np.random.default_rng(M * 1000 + N)
+    Ge = K if G == -1 else G
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    a = orc.f32_to_h16(0.25 * rng.standard_normal((M, K)).astype(np.float32))
+    s = orc.f32_to_h16((0.05 * rng.random((K // Ge, N))).astype(np.float32))
+    bias = orc.f32_to_h16(rng.standard_normal(N).astype(np.float32))
+    qw = orc.gptq_pack(q)
+    ref = orc.w4a16_gemm(a, qw, s, None, bias, G=Ge)
+    w = ops.w4a16_repack(i32(qw), to_dev(s), None, G)
+    out = ops.w4a16_gemm(to_dev(a), w, bias=to_dev(bias), split_k=split)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=1e-2)
+    # fp32 math on both sides: all but sum-order ties are bit-equal
+    assert (to_bits(out) == ref).mean() > 0.98
+    # run-to-run determinism (no atomics in the split-K path)
+    out2 = ops.w4a16_gemm(to_dev(a), w, bias=to_dev(bias), split_k=split)
+    assert torch.equal(out, out2)
+
+
+def test_w4a16_split_k_invariance_of_argmax():
+    """Greedy token ids must not depend on the split chosen: compare splits 1, 4, 8 on an
+    lm_head-like GEMM against the oracle's argmax."""
+    rng = np.random.default_rng(7)
+    M, K, N, G = 4, 2048, 1024, 128
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    a = orc.f32_to_h16(rng.standard_normal((M, K)).astype(np.float32))
+    s = orc.f32_to_h16((0.02 * rng.random((K // G, N)) + 0.01).astype(np.float32))
+    qw = orc.gptq_pack(q)
+    ref_ids = orc.argmax_h16(orc.w4a16_gemm(a, qw, s, None, None, G=G))
+    w = ops.w4a16_repack(i32(qw), to_dev(s), None, G)
+    for split in (1, 4, 8):
+        ids = ops.argmax(ops.w4a16_gemm(to_dev(a), w, split_k=split))
+        assert ids.cpu().numpy().tolist() == ref_ids.tolist()
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 1024, 256), (7, 14336 // 4, 512), (16, 512, 128)])
+def test_w4a16_fused_silu_mul(M, K, N):
+    rng = np.random.default_rng(3)
+    G = 128
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    x = orc.f32_to_h16(rng.standard_normal((M, 2 * K)).astype(np.float32))
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N))).astype(np.float32))
+    qw = orc.gptq_pack(q)
+    act = orc.silu_and_mul(x)
+    ref = orc.w4a16_gemm(act, qw, s, None, None, G=G)
+    w = ops.w4a16_repack(i32(qw), to_dev(s), None, G)
+    out = ops.w4a16_gemm(to_dev(x), w, fuse_silu_mul=True)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=2e-2)
+    # and equals the unfused HIP pipeline bit for bit up to fp32 sum order
+    act_d = torch.empty((M, K), dtype=torch.bfloat16, device=DEV)
+    ops.silu_and_mul(act_d, to_dev(x))
+    np.testing.assert_allclose(f32(to_bits(act_d)), f32(act), rtol=1e-2, atol=1e-3)
+    out2 = ops.w4a16_gemm(act_d, w)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(to_bits(out2)), rtol=1e-2, atol=1e-2)
+
+
+def test_w4a16_repack_device_matches_host():
+    rng = np.random.default_rng(11)
+    K, N, G = 256, 128, 64
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    z = rng.integers(0, 16, size=(K // G, N), dtype=np.int32)
+    s = torch.from_numpy(rng.random((K // G, N)).astype(np.float32)).to(torch.bfloat16)
+    for layout, src, zmode, qz in [(_lib.W_GPTQ, orc.gptq_pack(q), _lib.ZP_GPTQ_V1, orc.pack_cols(z)),
+                                   (_lib.W_AWQ, orc.pack_cols(q, True), _lib.ZP_AWQ, orc.pack_cols(z, True)),
+                                   (_lib.W_NSEQ, orc.pack_cols(q), _lib.ZP_NSEQ, orc.pack_cols(z))]:
+        host = ops.w4a16_repack(torch.from_numpy(src), s, torch.from_numpy(qz), G, layout, zmode)
+        dev = ops.w4a16_repack(i32(src), s.to(DEV), i32(qz), G, layout, zmode)
+        assert torch.equal(host.packed, dev.packed.cpu())
+        assert torch.equal(host.zc, dev.zc.cpu())
+
+
+def test_w4a16_rejects_bad_shapes():
+    s = torch.zeros((1, 48), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.w4a16_repack(torch.zeros((4, 48), dtype=torch.int32, device=DEV), s, None, 32)
+    w = ops.w4a16_repack(torch.zeros((4, 64), dtype=torch.int32, device=DEV),
+                         torch.zeros((1, 64), dtype=torch.bfloat16, device=DEV), None, 32)
+    with pytest.raises(RuntimeError, match="feature size"):
+        ops.w4a16_gemm(torch.zeros((1, 64), dtype=torch.bfloat16, device=DEV), w)
+    assert ops.w4a16_gemm(torch.zeros((0, 32), dtype=torch.bfloat16, device=DEV), w).shape == (0, 64)
+
+
+# ---------------------------------------------------------------------------
+# unquantized skinny linear
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N", [(1, 4096, 1000), (3, 768, 517), (8, 4096, 256), (13, 1024, 129), (2, 8192, 64)])
+def test_linear_skinny(M, K, N):
+    rng = np.random.default_rng(M + N)
+    a = orc.f32_to_h16(rng.standard_normal((M, K)).astype(np.float32))
+    w = orc.f32_to_h16((0.05 * rng.standard_normal((N, K))).astype(np.float32))
+    ref = orc.linear_h16(a, w)
+    out = ops.linear_skinny(to_dev(a), to_dev(w))
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1.6e-2, atol=1e-2)
+    assert (to_bits(out) == ref).mean() > 0.97
+
+
+# ---------------------------------------------------------------------------
+# norms, rope, activation (golden + oracle)
+# ---------------------------------------------------------------------------
+def test_rmsnorm_golden(golden):
+    g = golden("rmsnorm")
+    for tag in g["names"]:
+        tag = str(tag)
+        x, r, w = to_dev(g[tag + "_x"]), to_dev(g[tag + "_r"]), to_dev(g[tag + "_w"])
+        y = torch.empty_like(x)
+        ops.rms_norm(y, x, w, 1e-5)
+        assert (to_bits(y) == g[tag + "_kernel"]).mean() > 0.999, tag
+        np.testing.assert_allclose(f32(to_bits(y)), f32(g[tag + "_native"]), rtol=1.6e-2, atol=1e-3)
+        x2, r2 = x.clone(), r.clone()
+        ops.fused_add_rms_norm(x2, r2, w, 1e-5)
+        assert np.array_equal(to_bits(r2), g[tag + "_fused_kernel_res"]), tag
+        assert (to_bits(x2) == g[tag + "_fused_kernel"]).mean() > 0.999, tag
+
+
+def test_rmsnorm_edge_cases():
+    x = torch.randn(5, 64, device=DEV).to(torch.float16)
+    y = torch.empty_like(x)
+    ops.rms_norm(y, x, None, 1e-6)
+    ref = orc.rms_norm(to_bits(x), None, 1e-6, orc.FP16)
+    assert (to_bits(y) == ref).mean() > 0.99
+    # strided input rows (qkv slice), zero tokens
+    big = torch.randn(4, 256, device=DEV).to(torch.bfloat16)
+    xs = big[:, 64:192]
+    ys = torch.empty((4, 128), dtype=torch.bfloat16, device=DEV)
+    ops.rms_norm(ys, xs, None, 1e-5)
+    ref = orc.rms_norm(to_bits(xs.contiguous()), None, 1e-5)
+    assert (to_bits(ys) == ref).mean() > 0.99
+    ops.rms_norm(torch.empty((0, 64), dtype=torch.bfloat16, device=DEV),
+                 torch.empty((0, 64), dtype=torch.bfloat16, device=DEV), None, 1e-5)
+
+
+def test_rope_golden(golden):
+    g = golden("rope")
+    for tag in g["names"]:
+        tag = str(tag)
+        head, rot, neox, nh, nkv = [int(v) for v in g[tag + "_meta"]]
+        q, k = to_dev(g[tag + "_q"]), to_dev(g[tag + "_k"])
+        pos = torch.from_numpy(g[tag + "_pos"]).to(DEV)
+        ops.rotary_embedding(pos, q, k, head, to_dev(g[tag + "_cache"]), bool(neox))
+        qo, ko = orc.rotary_embedding(g[tag + "_pos"], g[tag + "_q"], g[tag + "_k"], g[tag + "_cache"], head, neox)
+        assert np.array_equal(to_bits(q), qo), tag  # same fp32 expression, one rounding
+        assert np.array_equal(to_bits(k), ko), tag
+        np.testing.assert_allclose(f32(to_bits(q)), f32(g[tag + "_qo"]), rtol=1.6e-2, atol=2e-2)
+
+
+def test_silu_and_mul():
+    x = torch.randn(7, 2 * 1000, device=DEV).to(torch.bfloat16) * 3
+    out = torch.empty((7, 1000), dtype=torch.bfloat16, device=DEV)
+    ops.silu_and_mul(out, x)
+    ref = orc.silu_and_mul(to_bits(x))
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1.6e-2, atol=1e-3)
+    assert (to_bits(out) == ref).mean() > 0.98
+
+
+# ---------------------------------------------------------------------------
+# KV cache + paged attention
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("bs,head", [(16, 128), (32, 64)])
+def test_reshape_and_cache(fp8, bs, head):
+    rng = np.random.default_rng(5)
+    T, kvh, nblk = 9, 2, 6
+    x = 16 if fp8 else 8
+    key = orc.f32_to_h16(rng.standard_normal((T, kvh, head)).astype(np.float32))
+    val = orc.f32_to_h16(rng.standard_normal((T, kvh, head)).astype(np.float32))
+    slots = rng.permutation(nblk * bs)[:T].astype(np.int64)
+    slots[3] = -1
+    cdt = np.uint8 if fp8 else np.uint16
+    kc_ref = np.zeros((nblk, kvh, head // x, bs, x), dtype=cdt)
+    vc_ref = np.zeros((nblk, kvh, head, bs), dtype=cdt)
+    ks, vs = (0.05, 0.02) if fp8 else (1.0, 1.0)
+    orc.reshape_and_cache(key, val, kc_ref, vc_ref, slots, fp8=fp8, k_scale=ks, v_scale=vs)
+    tdt = torch.uint8 if fp8 else torch.bfloat16
+    kc = torch.zeros((nblk, kvh, head // x, bs, x), dtype=tdt, device=DEV)
+    vc = torch.zeros((nblk, kvh, head, bs), dtype=tdt, device=DEV)
+    kst = torch.tensor(ks, dtype=torch.float32, device=DEV)
+    vst = torch.tensor(vs, dtype=torch.float32, device=DEV)
+    ops.reshape_and_cache(to_dev(key), to_dev(val), kc, vc, torch.from_numpy(slots).to(DEV),
+                          "fp8" if fp8 else "auto", kst, vst)
+    got_k = kc.cpu().numpy() if fp8 else to_bits(kc)
+    got_v = vc.cpu().numpy() if fp8 else to_bits(vc)
+    assert np.array_equal(got_k, kc_ref)
+    assert np.array_equal(got_v, vc_ref)
+    if fp8:  # convert_fp8 round trip as tests/kernels/attention/test_cache.py does
+        back = torch.empty(kc.shape, dtype=torch.bfloat16, device=DEV)
+        ops.convert_fp8(back, kc, ks)
+        expect = orc.f32_to_h16(orc.e4m3_to_f32(kc_ref) * np.float32(ks))
+        assert np.array_equal(to_bits(back), expect)
+
+
+def _run_paged(g, tag, varlen_rows=None):
+    H, KVH, D, bs, fp8 = [int(v) for v in g[tag + "_meta"]]
+    scale = float(g[tag + "_scale"][0])
+    q = to_dev(g[tag + "_q"])
+    if fp8:
+        kc = torch.from_numpy(g[tag + "_kc"]).to(DEV)
+        vc = torch.from_numpy(g[tag + "_vc"]).to(DEV)
+        ks, vs = [float(v) for v in g[tag + "_kv_scale"]]
+    else:
+        kc, vc = to_dev(g[tag + "_kc"]), to_dev(g[tag + "_vc"])
+        ks = vs = 1.0
+    bt = torch.from_numpy(g[tag + "_bt"]).to(DEV)
+    sl = torch.from_numpy(g[tag + "_sl"]).to(DEV)
+    alibi = torch.from_numpy(g[tag + "_alibi"]).to(DEV) if (tag + "_alibi") in g.files else None
+    S = q.shape[0]
+    max_len = int(g[tag + "_sl"].max())
+    P = (max_len + 255) // 256
+    out = torch.empty_like(q)
+    tmp = torch.empty((S, H, P, D), dtype=q.dtype, device=DEV)
+    es = torch.empty((S, H, P), dtype=torch.float32, device=DEV)
+    ml = torch.empty_like(es)
+    kst = torch.tensor(ks, dtype=torch.float32, device=DEV)
+    vst = torch.tensor(vs, dtype=torch.float32, device=DEV)
+    ops.paged_attention_rocm(out, es, ml, tmp, q, kc, vc, KVH, scale, bt, sl, None, bs, max_len, alibi,
+                             "fp8" if fp8 else "auto", kst, vst)
+    return out, fp8
+
+
+def test_paged_attention_golden(golden):
+    """Fixtures follow tests/kernels/attention/test_attention.py:124-291; tolerance of :288-291."""
+    g = golden("paged_attn")
+    for tag in g["names"]:
+        tag = str(tag)
+        out, fp8 = _run_paged(g, tag)
+        atol = 1e-2 if fp8 else 1e-3
+        np.testing.assert_allclose(f32(to_bits(out)), f32(g[tag + "_ref"]), rtol=1e-5, atol=atol, err_msg=tag)
+
+
+@pytest.mark.parametrize("H,KVH,D,bs,fp8", [(32, 8, 128, 16, False), (64, 8, 128, 16, True), (40, 40, 64, 32, False),
+                                            (16, 1, 128, 32, False)])
+def test_paged_attention_vs_oracle(H, KVH, D, bs, fp8):
+    rng = np.random.default_rng(H + D)
+    lens = [1, 15, 16, 255, 256, 257, 1000]
+    S = len(lens)
+    nblk = 80
+    x = 16 if fp8 else 8
+    scale = 1.0 / D ** 0.5
+    q = orc.f32_to_h16(rng.uniform(-1, 1, (S, H, D)).astype(np.float32))
+    kf = rng.uniform(-1, 1, (nblk, KVH, D // x, bs, x)).astype(np.float32)
+    vf = rng.uniform(-1, 1, (nblk, KVH, D, bs)).astype(np.float32)
+    ks, vs = (1 / 64, 1 / 32) if fp8 else (1.0, 1.0)
+    if fp8:
+        kc, vc = orc.f32_to_e4m3(kf / ks), orc.f32_to_e4m3(vf / vs)
+        kcd, vcd = torch.from_numpy(kc).to(DEV), torch.from_numpy(vc).to(DEV)
+    else:
+        kc, vc = orc.f32_to_h16(kf), orc.f32_to_h16(vf)
+        kcd, vcd = to_dev(kc), to_dev(vc)
+    maxb = (max(lens) + bs - 1) // bs
+    bt = rng.integers(0, nblk, size=(S, maxb)).astype(np.int32)
+    sl = np.array(lens, dtype=np.int32)
+    ref = orc.paged_attention(q, kc, vc, bt, sl, scale, fp8=fp8, k_scale=ks, v_scale=vs)
+    P = (max(lens) + 255) // 256
+    qd = to_dev(q)
+    out = torch.empty_like(qd)
+    tmp = torch.empty((S, H, P, D), dtype=qd.dtype, device=DEV)
+    es = torch.empty((S, H, P), dtype=torch.float32, device=DEV)
+    ml = torch.empty_like(es)
+    kst = torch.tensor(ks, dtype=torch.float32, device=DEV)
+    vst = torch.tensor(vs, dtype=torch.float32, device=DEV)
+    ops.paged_attention_rocm(out, es, ml, tmp, qd, kcd, vcd, KVH, scale, torch.from_numpy(bt).to(DEV),
+                             torch.from_numpy(sl).to(DEV), None, bs, max(lens), None, "fp8" if fp8 else "auto", kst, vst)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-5, atol=2e-3 if not fp8 else 1e-2)
+
+
+def test_paged_attention_skips_prompt_rows_and_ignores_stale_cache():
+    """Rows whose query length != 1 are left untouched (csrc/rocm/attention.cu:351-354), and
+    cache slots past seq_len may hold NaN without leaking into the output."""
+    rng = np.random.default_rng(9)
+    H, KVH, D, bs = 8, 2, 128, 16
+    S, nblk = 3, 8
+    q = to_dev(orc.f32_to_h16(rng.uniform(-1, 1, (S + 2, H, D)).astype(np.float32)))
+    kc = torch.full((nblk, KVH, D // 8, bs, 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+    vc = torch.full((nblk, KVH, D, bs), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lens = np.array([5, 20, 3], dtype=np.int32)
+    bt = np.array([[0, 1], [2, 3], [4, 5]], dtype=np.int32)
+    kf = rng.uniform(-1, 1, (nblk, KVH, D // 8, bs, 8)).astype(np.float32)
+    vf = rng.uniform(-1, 1, (nblk, KVH, D, bs)).astype(np.float32)
+    kcn, vcn = orc.f32_to_h16(kf), orc.f32_to_h16(vf)
+    for s in range(S):
+        for j in range(lens[s]):
+            b, o = bt[s, j // bs], j % bs
+            kc[b, :, :, o, :] = to_dev(kcn[b, :, :, o, :])
+            vc[b, :, :, o] = to_dev(vcn[b, :, :, o])
+    qsl = torch.tensor([0, 1, 4, 5], dtype=torch.int32, device=DEV)  # row 1 is a 3-token prompt row
+    out = torch.full((S + 2, H, D), 7.0, dtype=torch.bfloat16, device=DEV)
+    one = torch.ones((), dtype=torch.float32, device=DEV)
+    ops.paged_attention_rocm(out, None, None, None, q, kc, vc, KVH, 0.1, torch.from_numpy(bt).to(DEV),
+                             torch.from_numpy(lens).to(DEV), qsl, bs, 20, None, "auto", one, one)
+    o = out.float().cpu()
+    assert torch.all(o[1:4] == 7.0)
+    assert torch.isfinite(o[0]).all() and torch.isfinite(o[4]).all()
+    qrows = to_bits(q)[[0, 4]]
+    ref = orc.paged_attention(qrows, kcn, vcn, bt[[0, 2]], lens[[0, 2]], 0.1)
+    np.testing.assert_allclose(f32(to_bits(out[[0, 4]])), f32(ref), rtol=1e-5, atol=2e-3)
+
+
+@pytest.mark.parametrize("H,KVH,D,bs,fp8", [(8, 2, 128, 16, False), (4, 4, 64, 32, False), (16, 2, 128, 16, True)])
+def test_paged_prefill_attention_vs_oracle(H, KVH, D, bs, fp8):
+    """Prompt rows: write K/V with reshape_and_cache, attend through the cache, compare with
+    dense causal attention of the oracle (and a decode row mixed in)."""
+    rng = np.random.default_rng(D + H)
+    qlens = [37, 1, 300]
+    ctx0 = [0, 40, 20]  # tokens already in the cache before this step
+    S = len(qlens)
+    x = 16 if fp8 else 8
+    nblk = 64
+    scale = 1.0 / D ** 0.5
+    ks, vs = (1 / 32, 1 / 32) if fp8 else (1.0, 1.0)
+    tdt = torch.uint8 if fp8 else torch.bfloat16
+    kc = torch.zeros((nblk, KVH, D // x, bs, x), dtype=tdt, device=DEV)
+    vc = torch.zeros((nblk, KVH, D, bs), dtype=tdt, device=DEV)
+    kst = torch.tensor(ks, dtype=torch.float32, device=DEV)
+    vst = torch.tensor(vs, dtype=torch.float32, device=DEV)
+    seq_lens = [c + q for c, q in zip(ctx0, qlens)]
+    maxb = (max(seq_lens) + bs - 1) // bs
+    perm = rng.permutation(nblk)
+    bt = perm[: S * maxb].reshape(S, maxb).astype(np.int32)
+    allk, allv, allq, slots_new = [], [], [], []
+    refs = []
+    for s in range(S):
+        L = seq_lens[s]
+        k = orc.f32_to_h16(rng.uniform(-1, 1, (L, KVH, D)).astype(np.float32))
+        v = orc.f32_to_h16(rng.uniform(-1, 1, (L, KVH, D)).astype(np.float32))
+        q = orc.f32_to_h16(rng.uniform(-1, 1, (L, H, D)).astype(np.float32))
+        slots = np.array([bt[s, j // bs] * bs + j % bs for j in range(L)], dtype=np.int64)
+        ops.reshape_and_cache(to_dev(k), to_dev(v), kc, vc, torch.from_numpy(slots).to(DEV),
+                              "fp8" if fp8 else "auto", kst, vst)
+        if fp8:  # the oracle attends the quantised values the cache holds
+            k = orc.f32_to_h16(orc.e4m3_to_f32(orc.f32_to_e4m3(orc.h16_to_f32(k) / np.float32(ks))) * np.float32(ks))
+            v = orc.f32_to_h16(orc.e4m3_to_f32(orc.f32_to_e4m3(orc.h16_to_f32(v) / np.float32(vs))) * np.float32(vs))
+        full = orc.prefill_attention(q, k, v, scale)
+        refs.append(full[ctx0[s]:])
+        allq.append(q[ctx0[s]:])
+    qcat = np.concatenate(allq, 0)
+    ref = np.concatenate(refs, 0)
+    T = qcat.shape[0]
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(qlens)]).astype(np.int32), device=DEV)
+    P = (max(seq_lens) + 255) // 256
+    qd = to_dev(qcat)
+    out = torch.empty_like(qd)
+    tmp = torch.empty((T, H, P, D), dtype=qd.dtype, device=DEV)
+    es = torch.empty((T, H, P), dtype=torch.float32, device=DEV)
+    ml = torch.empty_like(es)
+    ops.paged_prefill_attention(out, es, ml, tmp, qd, kc, vc, KVH, scale, torch.from_numpy(bt).to(DEV),
+                                torch.tensor(seq_lens, dtype=torch.int32, device=DEV), qsl, max(qlens), bs,
+                                max(seq_lens), None, "fp8" if fp8 else "auto", kst, vst)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-5, atol=1e-2 if fp8 else 3e-3)
+
+
+# ---------------------------------------------------------------------------
+# sampler inner loop
+# ---------------------------------------------------------------------------
+def test_sampler_golden(golden):
+    g = golden("sampler")
+    logits = to_dev(g["logits"])
+    assert ops.argmax(logits).cpu().numpy().tolist() == g["argmax"].tolist()
+    assert ops.argmax(logits.float()).cpu().numpy().tolist() == g["argmax"].tolist()
+    lg = logits.float().contiguous()
+    ops.apply_repetition_penalties(lg, torch.from_numpy(g["prompt_mask"]).to(DEV),
+                                   torch.from_numpy(g["output_mask"]).to(DEV), torch.from_numpy(g["penalties"]).to(DEV))
+    ref = orc.apply_repetition_penalties(f32(g["logits"]), g["prompt_mask"], g["output_mask"], g["penalties"])
+    assert np.array_equal(lg.cpu().numpy(), ref)
+    np.testing.assert_allclose(lg.cpu().numpy(), g["penalized"], rtol=2e-7, atol=0)
+
+
+def test_argmax_full_vocab_ties_and_strides():
+    V = 128256
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((5, V)).astype(np.float32)
+    x[0, 128255] = 100.0
+    x[1, 0] = 100.0
+    x[2, 777] = 50.0
+    x[2, 90000] = 50.0
+    x[3, :] = -np.inf
+    bits = orc.f32_to_h16(x)
+    ids = ops.argmax(to_dev(bits))
+    assert ids.cpu().numpy().tolist() == orc.argmax_h16(bits).tolist()
+    assert ids.cpu().numpy().tolist()[:4] == [128255, 0, 777, 0]
+    wide = torch.zeros((5, V + 64), dtype=torch.float32, device=DEV)
+    wide[:, :V] = torch.from_numpy(x).to(DEV)
+    assert ops.argmax(wide[:, :V]).cpu().numpy().tolist() == orc.argmax_f32(x).tolist()

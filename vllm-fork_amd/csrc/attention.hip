@@ -1,0 +1,406 @@
+// Paged attention over the ROCM_ATTN cache layout for gfx950.
+//   K cache [blocks, kv_heads, head/x, block_size, x]  (x = 8 for 16-bit, 16 for fp8)
+//   V cache [blocks, kv_heads, head, block_size]
+// One workgroup (4 waves) handles one (query block, 256-token partition, kv head); each
+// wave owns 64 tokens of the partition.  The 16 columns of every MFMA tile are
+// (query token, query head of the kv head's group) pairs, so the same kernel serves
+// decode (one query token) and prompt rows (several query tokens with per-column causal
+// limits) reading K/V back from the cache.
+//
+//   S^T = K * Q^T      v_mfma_f32_16x16x32: rows = tokens, columns = query columns
+//   O^T = V^T * P^T    rows = head dims, columns = query columns; the k index of this
+//                      product is permuted so that each lane's P fragment is exactly the
+//                      S^T registers it already holds (no cross-lane traffic)
+// Softmax statistics are combined across waves through LDS; per-partition results go to
+// tmp_out / exp_sums / max_logits and a second kernel merges partitions.
+#include "common.h"
+
+namespace mi355q {
+
+struct PAParams {
+  void* out;
+  float* exp_sums;
+  float* max_logits;
+  void* tmp_out;
+  const uint16_t* q;
+  int64_t q_stride;
+  const void* kc;
+  const void* vc;
+  int64_t kv_block_stride, kv_head_stride;
+  int num_seqs, num_heads, num_kv_heads;
+  float scale;
+  const int32_t* block_tables;
+  int max_blocks;
+  const int32_t* seq_lens;
+  const int32_t* qsl;  // query_start_loc or null
+  int bs;
+  int max_parts;
+  const float* alibi;
+  const float* k_scale;
+  const float* v_scale;
+  int varlen;          // 0: decode rows only, 1: every row, several query tokens per block
+  int qblocks_per_seq; // varlen: ceil(max_query_len / QB)
+  int gp;              // columns per query token (power of two >= group size)
+};
+
+template <typename DT>
+__device__ inline u32x2 fp8x4_to_h16(uint32_t v) {
+  const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(v, false);
+  const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8(v, true);
+  u32x2 r;
+  r[0] = pack2<DT>(lo[0], lo[1]);
+  r[1] = pack2<DT>(hi[0], hi[1]);
+  return r;
+}
+
+template <typename DT, int HEAD, bool KVFP8>
+__global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) {
+  __shared__ float s_max[4][16];
+  __shared__ float s_sum[4][16];
+  __shared__ __attribute__((aligned(16))) float s_out[4][16][HEAD];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kq = lane >> 4, col = lane & 15;
+  const int g = p.num_heads / p.num_kv_heads;
+  const int gp = p.gp, QB = 16 / gp;
+
+  int seq, q0, qlen, qstart;
+  if (p.varlen) {
+    seq = blockIdx.x / p.qblocks_per_seq;
+    q0 = (blockIdx.x % p.qblocks_per_seq) * QB;
+    qstart = p.qsl[seq];
+    qlen = p.qsl[seq + 1] - qstart;
+    if (q0 >= qlen) return;
+  } else {
+    seq = blockIdx.x;
+    q0 = 0;
+    qlen = 1;
+    qstart = seq;
+    if (p.qsl) {
+      qstart = p.qsl[seq];
+      if (p.qsl[seq + 1] - qstart != 1) return;  // prompt rows are not handled here
+    }
+  }
+  const int seq_len = p.seq_lens[seq];
+  const int q_in_blk = min(QB, qlen - q0);
+  const int blk_ctx = seq_len - qlen + q0 + q_in_blk;  // tokens visible to the last column
+  const int part = blockIdx.y;
+  const int p0 = part * MI355Q_PA_PARTITION;
+  if (p0 >= blk_ctx) return;
+  const int kvh = blockIdx.z;
+
+  // this lane's query column
+  const int qi = col / gp, hi = col % gp;
+  const bool col_valid = hi < g && qi < q_in_blk;
+  const int ctx_c = col_valid ? seq_len - qlen + q0 + qi + 1 : 0;
+  const int qrow = qstart + q0 + min(qi, q_in_blk - 1);
+  const int head = kvh * g + min(hi, g - 1);
+
+  const float scale = KVFP8 ? p.scale * (*p.k_scale) : p.scale;
+  const float slope = p.alibi ? p.alibi[head] : 0.f;
+
+  // ---- Q fragments (B operand): column = this lane's query column --------------------
+  constexpr int DS = HEAD / 32;
+  u32x4 qf[DS];
+  {
+    const uint16_t* qp = p.q + (size_t)qrow * p.q_stride + (size_t)head * HEAD;
+#pragma unroll
+    for (int ds = 0; ds < DS; ds++) {
+      // 16-bit cache: k index of step ds is d = 32 ds + 8 kq + j
+      // fp8 cache   : one 16-byte K load covers d = 16 (4 (ds/2) + kq) + 8 (ds&1) + j
+      const int d0 = KVFP8 ? 16 * (4 * (ds >> 1) + kq) + 8 * (ds & 1) : 32 * ds + 8 * kq;
+      qf[ds] = *reinterpret_cast<const u32x4*>(qp + d0);
+    }
+  }
+
+  const int32_t* table = p.block_tables + (size_t)seq * p.max_blocks;
+  const int wave_t0 = p0 + wave * 64;
+
+  // ---- S^T = K Q^T for the wave's four 16-token tiles ----------------------------------
+  f32x4 st[4];
+  int phys[4];
+#pragma unroll
+  for (int T = 0; T < 4; T++) {
+    st[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int t0 = wave_t0 + T * 16;
+    phys[T] = -1;
+    if (t0 < blk_ctx) {
+      phys[T] = table[t0 / p.bs];
+      const int off = t0 % p.bs + col;  // this lane's token row of the tile
+      if constexpr (!KVFP8) {
+        const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.kc) +
+                             (size_t)phys[T] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+#pragma unroll
+        for (int ds = 0; ds < DS; ds++) {
+          const u32x4 kf = *reinterpret_cast<const u32x4*>(kb + ((size_t)(ds * 4 + kq) * p.bs + off) * 8);
+          st[T] = mfma16<DT>(kf, qf[ds], st[T]);
+        }
+      } else {
+        const uint8_t* kb = reinterpret_cast<const uint8_t*>(p.kc) +
+                            (size_t)phys[T] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+#pragma unroll
+        for (int sp = 0; sp < DS / 2; sp++) {
+          const u32x4 raw = *reinterpret_cast<const u32x4*>(kb + ((size_t)(sp * 4 + kq) * p.bs + off) * 16);
+          const u32x2 a0 = fp8x4_to_h16<DT>(raw[0]), a1 = fp8x4_to_h16<DT>(raw[1]);
+          const u32x2 b0 = fp8x4_to_h16<DT>(raw[2]), b1 = fp8x4_to_h16<DT>(raw[3]);
+          st[T] = mfma16<DT>(u32x4{a0[0], a0[1], a1[0], a1[1]}, qf[2 * sp], st[T]);
+          st[T] = mfma16<DT>(u32x4{b0[0], b0[1], b1[0], b1[1]}, qf[2 * sp + 1], st[T]);
+        }
+      }
+    }
+  }
+
+  // ---- logits, partition max / sum per column ------------------------------------------
+  float mx = -INFINITY;
+#pragma unroll
+  for (int T = 0; T < 4; T++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int tok = wave_t0 + T * 16 + 4 * kq + r;
+      float v = st[T][r] * scale + slope * (float)(tok - ctx_c + 1);
+      v = tok < ctx_c ? v : -INFINITY;
+      st[T][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (kq == 0) s_max[wave][col] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_max[0][col], s_max[1][col]), fmaxf(s_max[2][col], s_max[3][col]));
+  const float mref = mx == -INFINITY ? 0.f : mx;
+  float sum = 0.f;
+#pragma unroll
+  for (int T = 0; T < 4; T++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float e = __expf(st[T][r] - mref);
+      st[T][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  if (kq == 0) s_sum[wave][col] = sum;
+  __syncthreads();
+  sum = (s_sum[0][col] + s_sum[1][col]) + (s_sum[2][col] + s_sum[3][col]);
+  const float inv = 1.0f / (sum + 1e-6f);
+
+  // ---- O^T += V^T P^T ---------------------------------------------------------------------
+  constexpr int DTILES = HEAD / 16;
+  f32x4 o[DTILES];
+#pragma unroll
+  for (int dt = 0; dt < DTILES; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s2 = 0; s2 < 2; s2++) {
+    const int Te = 2 * s2, To = 2 * s2 + 1;
+    if (phys[Te] < 0) break;  // wave-uniform: tiles are visited in token order
+    // P fragment: k element j <-> token 4 kq + j of the even tile (j < 4), of the odd tile (j >= 4)
+    u32x4 pf;
+    pf[0] = pack2<DT>(st[Te][0] * inv, st[Te][1] * inv);
+    pf[1] = pack2<DT>(st[Te][2] * inv, st[Te][3] * inv);
+    pf[2] = pack2<DT>(st[To][0] * inv, st[To][1] * inv);
+    pf[3] = pack2<DT>(st[To][2] * inv, st[To][3] * inv);
+    // tokens at or past seq_len hold unwritten cache memory: force their V to zero
+    const int te0 = wave_t0 + Te * 16 + 4 * kq, to0 = wave_t0 + To * 16 + 4 * kq;
+    const int ne = min(max(seq_len - te0, 0), 4), no = min(max(seq_len - to0, 0), 4);
+    const uint32_t me0 = ne >= 2 ? 0xffffffffu : (ne == 1 ? 0x0000ffffu : 0u);
+    const uint32_t me1 = ne >= 4 ? 0xffffffffu : (ne == 3 ? 0x0000ffffu : 0u);
+    const uint32_t mo0 = no >= 2 ? 0xffffffffu : (no == 1 ? 0x0000ffffu : 0u);
+    const uint32_t mo1 = no >= 4 ? 0xffffffffu : (no == 3 ? 0x0000ffffu : 0u);
+    const int offe = (wave_t0 + Te * 16) % p.bs + 4 * kq;
+    const int offo = (wave_t0 + To * 16) % p.bs + 4 * kq;
+    const bool odd_ok = phys[To] >= 0;
+    if constexpr (!KVFP8) {
+      const uint16_t* vbe = reinterpret_cast<const uint16_t*>(p.vc) +
+                            (size_t)phys[Te] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+      const uint16_t* vbo = reinterpret_cast<const uint16_t*>(p.vc) +
+                            (size_t)(odd_ok ? phys[To] : phys[Te]) * p.kv_block_stride +
+                            (size_t)kvh * p.kv_head_stride;
+#pragma unroll
+      for (int dt = 0; dt < DTILES; dt++) {
+        const size_t drow = (size_t)(dt * 16 + col) * p.bs;
+        const u32x2 ve = *reinterpret_cast<const u32x2*>(vbe + drow + offe);
+        u32x2 vo = u32x2{0u, 0u};
+        if (odd_ok) vo = *reinterpret_cast<const u32x2*>(vbo + drow + offo);
+        const u32x4 vf = u32x4{ve[0] & me0, ve[1] & me1, vo[0] & mo0, vo[1] & mo1};
+        o[dt] = mfma16<DT>(vf, pf, o[dt]);
+      }
+    } else {
+      const uint8_t* vbe = reinterpret_cast<const uint8_t*>(p.vc) +
+                           (size_t)phys[Te] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+      const uint8_t* vbo = reinterpret_cast<const uint8_t*>(p.vc) +
+                           (size_t)(odd_ok ? phys[To] : phys[Te]) * p.kv_block_stride +
+                           (size_t)kvh * p.kv_head_stride;
+#pragma unroll
+      for (int dt = 0; dt < DTILES; dt++) {
+        const size_t drow = (size_t)(dt * 16 + col) * p.bs;
+        const u32x2 ve = fp8x4_to_h16<DT>(*reinterpret_cast<const uint32_t*>(vbe + drow + offe));
+        u32x2 vo = u32x2{0u, 0u};
+        if (odd_ok) vo = fp8x4_to_h16<DT>(*reinterpret_cast<const uint32_t*>(vbo + drow + offo));
+        const u32x4 vf = u32x4{ve[0] & me0, ve[1] & me1, vo[0] & mo0, vo[1] & mo1};
+        o[dt] = mfma16<DT>(vf, pf, o[dt]);
+      }
+    }
+  }
+
+  // ---- cross-wave sum of O, store ---------------------------------------------------------
+  const float vs = KVFP8 ? *p.v_scale : 1.0f;
+#pragma unroll
+  for (int dt = 0; dt < DTILES; dt++)
+    *reinterpret_cast<f32x4*>(&s_out[wave][col][dt * 16 + 4 * kq]) = o[dt] * vs;
+  __syncthreads();
+
+  const bool single = p.max_parts == 1;
+  for (int idx = threadIdx.x; idx < 16 * HEAD; idx += 256) {
+    const int c = idx / HEAD, d = idx - c * HEAD;
+    const int cqi = c / gp, chi = c % gp;
+    if (chi >= g || cqi >= q_in_blk) continue;
+    const float v = (s_out[0][c][d] + s_out[1][c][d]) + (s_out[2][c][d] + s_out[3][c][d]);
+    const size_t row = (size_t)(qstart + q0 + cqi);
+    const int h = kvh * g + chi;
+    if (single)
+      reinterpret_cast<uint16_t*>(p.out)[(row * p.num_heads + h) * HEAD + d] = DT::from_f32(v);
+    else
+      reinterpret_cast<uint16_t*>(p.tmp_out)[((row * p.num_heads + h) * p.max_parts + part) * HEAD + d] =
+          DT::from_f32(v);
+  }
+  if (!single && wave == 0 && kq == 0 && col_valid) {
+    const size_t row = (size_t)(qstart + q0 + qi);
+    const size_t o2 = (row * p.num_heads + (kvh * g + hi)) * p.max_parts + part;
+    p.exp_sums[o2] = sum;
+    p.max_logits[o2] = mx;
+  }
+}
+
+// merge partitions: out = sum_p tmp_p w_p / (sum_p w_p + 1e-6), w_p = exp_sum_p exp(max_p - max)
+template <typename DT, int HEAD>
+__global__ __launch_bounds__(HEAD) void paged_attention_reduce_kernel(const PAParams p, int max_qlen) {
+  const int h = blockIdx.x;
+  int seq, qi, qstart, qlen;
+  if (p.varlen) {
+    seq = blockIdx.y / max_qlen;
+    qi = blockIdx.y % max_qlen;
+    qstart = p.qsl[seq];
+    qlen = p.qsl[seq + 1] - qstart;
+    if (qi >= qlen) return;
+  } else {
+    seq = blockIdx.y;
+    qi = 0;
+    qlen = 1;
+    qstart = seq;
+    if (p.qsl) {
+      qstart = p.qsl[seq];
+      if (p.qsl[seq + 1] - qstart != 1) return;
+    }
+  }
+  const int ctx = p.seq_lens[seq] - qlen + qi + 1;
+  const int nparts = (ctx + MI355Q_PA_PARTITION - 1) / MI355Q_PA_PARTITION;
+  const size_t row = (size_t)(qstart + qi);
+  const size_t base = (row * p.num_heads + h) * p.max_parts;
+  float gmax = -INFINITY;
+  for (int i = 0; i < nparts; i++) gmax = fmaxf(gmax, p.max_logits[base + i]);
+  float wsum = 0.f, acc = 0.f;
+  const uint16_t* tmp = reinterpret_cast<const uint16_t*>(p.tmp_out) + base * HEAD + threadIdx.x;
+  for (int i = 0; i < nparts; i++) {
+    const float w = p.exp_sums[base + i] * __expf(p.max_logits[base + i] - gmax);
+    wsum += w;
+    acc += DT::to_f32(tmp[(size_t)i * HEAD]) * w;
+  }
+  reinterpret_cast<uint16_t*>(p.out)[(row * p.num_heads + h) * HEAD + threadIdx.x] =
+      DT::from_f32(acc / (wsum + 1e-6f));
+}
+
+template <typename DT>
+static int launch_pa(const PAParams& p, int head_size, int kv_fp8, int qblocks, int max_qlen,
+                     hipStream_t stream) {
+  dim3 grid(qblocks, p.max_parts, p.num_kv_heads), block(256);
+#define MI355Q_PA(H, F8) hipLaunchKernelGGL((paged_attention_kernel<DT, H, F8>), grid, block, 0, stream, p)
+  if (head_size == 128) { if (kv_fp8) MI355Q_PA(128, true); else MI355Q_PA(128, false); }
+  else { if (kv_fp8) MI355Q_PA(64, true); else MI355Q_PA(64, false); }
+#undef MI355Q_PA
+  if (int e = check_launch("paged_attention_kernel")) return e;
+  if (p.max_parts > 1) {
+    dim3 rgrid(p.num_heads, p.num_seqs * max_qlen);
+    if (head_size == 128)
+      hipLaunchKernelGGL((paged_attention_reduce_kernel<DT, 128>), rgrid, dim3(128), 0, stream, p, max_qlen);
+    else
+      hipLaunchKernelGGL((paged_attention_reduce_kernel<DT, 64>), rgrid, dim3(64), 0, stream, p, max_qlen);
+    if (int e = check_launch("paged_attention_reduce_kernel")) return e;
+  }
+  return MI355Q_OK;
+}
+
+static int pa_common(PAParams& p, int head_size, int block_size, int max_seq_len, int dtype,
+                     int kv_fp8, const char* what) {
+  MI355Q_REQUIRE(dtype == MI355Q_BF16 || dtype == MI355Q_FP16, "%s: dtype must be bf16 or fp16", what);
+  MI355Q_REQUIRE(head_size == 64 || head_size == 128, "%s: head_size %d not in {64,128}", what, head_size);
+  MI355Q_REQUIRE(block_size > 0 && block_size % 16 == 0, "%s: block_size %d must be a multiple of 16", what, block_size);
+  MI355Q_REQUIRE(p.num_kv_heads > 0 && p.num_heads % p.num_kv_heads == 0, "%s: heads %d / kv heads %d", what, p.num_heads, p.num_kv_heads);
+  const int g = p.num_heads / p.num_kv_heads;
+  MI355Q_REQUIRE(g >= 1 && g <= 16, "%s: unsupported gqa ratio %d", what, g);
+  MI355Q_REQUIRE(p.out && p.q && p.kc && p.vc && p.block_tables && p.seq_lens, "%s: null pointer", what);
+  if (kv_fp8) MI355Q_REQUIRE(p.k_scale && p.v_scale, "%s: fp8 cache needs k_scale/v_scale", what);
+  MI355Q_REQUIRE(p.q_stride % 8 == 0 && ((uintptr_t)p.q & 15) == 0, "%s: query must be 16-byte aligned", what);
+  MI355Q_REQUIRE(max_seq_len > 0, "%s: max_seq_len %d", what, max_seq_len);
+  p.max_parts = (max_seq_len + MI355Q_PA_PARTITION - 1) / MI355Q_PA_PARTITION;
+  if (p.max_parts > 1)
+    MI355Q_REQUIRE(p.exp_sums && p.max_logits && p.tmp_out, "%s: partition scratch required for max_seq_len > 256", what);
+  int gp = 1;
+  while (gp < g) gp <<= 1;
+  p.gp = gp;
+  return 0;
+}
+
+}  // namespace mi355q
+
+using namespace mi355q;
+
+extern "C" int mi355q_paged_attention(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                                      const void* query, int64_t q_stride, const void* key_cache,
+                                      const void* value_cache, int64_t kv_block_stride,
+                                      int64_t kv_head_stride, int num_seqs, int num_heads,
+                                      int num_kv_heads, int head_size, float scale,
+                                      const int32_t* block_tables, int max_blocks_per_seq,
+                                      const int32_t* seq_lens, const int32_t* query_start_loc,
+                                      int block_size, int max_seq_len, const float* alibi_slopes,
+                                      int dtype, int kv_fp8, const float* k_scale,
+                                      const float* v_scale, mi355q_stream_t stream) {
+  PAParams p;
+  p.out = out; p.exp_sums = exp_sums; p.max_logits = max_logits; p.tmp_out = tmp_out;
+  p.q = (const uint16_t*)query; p.q_stride = q_stride; p.kc = key_cache; p.vc = value_cache;
+  p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  p.num_seqs = num_seqs; p.num_heads = num_heads; p.num_kv_heads = num_kv_heads; p.scale = scale;
+  p.block_tables = block_tables; p.max_blocks = max_blocks_per_seq; p.seq_lens = seq_lens;
+  p.qsl = query_start_loc; p.bs = block_size; p.alibi = alibi_slopes; p.k_scale = k_scale;
+  p.v_scale = v_scale; p.varlen = 0; p.qblocks_per_seq = 1;
+  if (num_seqs == 0) return MI355Q_OK;
+  if (int e = pa_common(p, head_size, block_size, max_seq_len, dtype, kv_fp8, "paged_attention")) return e;
+  if (dtype == MI355Q_BF16) return launch_pa<BF16>(p, head_size, kv_fp8, num_seqs, 1, (hipStream_t)stream);
+  return launch_pa<FP16>(p, head_size, kv_fp8, num_seqs, 1, (hipStream_t)stream);
+}
+
+extern "C" int mi355q_paged_prefill_attention(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+    int64_t q_stride, const void* key_cache, const void* value_cache, int64_t kv_block_stride,
+    int64_t kv_head_stride, int num_seqs, int num_heads, int num_kv_heads, int head_size,
+    float scale, const int32_t* block_tables, int max_blocks_per_seq, const int32_t* seq_lens,
+    const int32_t* query_start_loc, int max_query_len, int block_size, int max_seq_len,
+    const float* alibi_slopes, int dtype, int kv_fp8, const float* k_scale, const float* v_scale,
+    mi355q_stream_t stream) {
+  PAParams p;
+  p.out = out; p.exp_sums = exp_sums; p.max_logits = max_logits; p.tmp_out = tmp_out;
+  p.q = (const uint16_t*)query; p.q_stride = q_stride; p.kc = key_cache; p.vc = value_cache;
+  p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  p.num_seqs = num_seqs; p.num_heads = num_heads; p.num_kv_heads = num_kv_heads; p.scale = scale;
+  p.block_tables = block_tables; p.max_blocks = max_blocks_per_seq; p.seq_lens = seq_lens;
+  p.qsl = query_start_loc; p.bs = block_size; p.alibi = alibi_slopes; p.k_scale = k_scale;
+  p.v_scale = v_scale; p.varlen = 1;
+  if (num_seqs == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(query_start_loc != nullptr && max_query_len > 0, "paged_prefill_attention: query_start_loc and max_query_len are required");
+  if (int e = pa_common(p, head_size, block_size, max_seq_len, dtype, kv_fp8, "paged_prefill_attention")) return e;
+  const int QB = 16 / p.gp;
+  p.qblocks_per_seq = (max_query_len + QB - 1) / QB;
+  const int qblocks = num_seqs * p.qblocks_per_seq;
+  if (dtype == MI355Q_BF16) return launch_pa<BF16>(p, head_size, kv_fp8, qblocks, max_query_len, (hipStream_t)stream);
+  return launch_pa<FP16>(p, head_size, kv_fp8, qblocks, max_query_len, (hipStream_t)stream);
+}

@@ -1,0 +1,120 @@
+// Shared device helpers for the gfx950 kernels of libmi355q.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mi355q.h"
+
+namespace mi355q {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// error plumbing (capi.cpp)
+int set_error(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MI355Q_REQUIRE(cond, ...)                              \
+  do {                                                         \
+    if (!(cond)) return set_error(MI355Q_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+// ---- 16-bit float <-> f32 -------------------------------------------------
+struct BF16 {
+  static constexpr int id = MI355Q_BF16;
+  static constexpr uint32_t int4_magic = 0x43004300u;  // bf16(128) in both halves
+  static constexpr float int4_bias = 128.0f;
+  static constexpr uint32_t ones = 0x3F803F80u;
+  __host__ __device__ static inline float to_f32(uint16_t h) {
+    union { uint32_t u; float f; } c;
+    c.u = (uint32_t)h << 16;
+    return c.f;
+  }
+  // round to nearest even; NaN stays NaN
+  __host__ __device__ static inline uint16_t from_f32(float f) {
+    union { float f; uint32_t u; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  }
+};
+
+struct FP16 {
+  static constexpr int id = MI355Q_FP16;
+  static constexpr uint32_t int4_magic = 0x64006400u;  // fp16(1024)
+  static constexpr float int4_bias = 1024.0f;
+  static constexpr uint32_t ones = 0x3C003C00u;
+  __device__ static inline float to_f32(uint16_t h) {
+    return (float)__builtin_bit_cast(_Float16, h);
+  }
+  __device__ static inline uint16_t from_f32(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+  }
+};
+
+template <typename DT>
+__device__ inline uint32_t pack2(float lo, float hi) {
+  return (uint32_t)DT::from_f32(lo) | ((uint32_t)DT::from_f32(hi) << 16);
+}
+
+template <typename DT>
+__device__ inline f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c);
+template <>
+__device__ inline f32x4 mfma16<BF16>(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ inline f32x4 mfma16<FP16>(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// ---- OCP e4m3fn (gfx950 hardware converts) ---------------------------------
+__device__ inline f32x2 fp8x2_to_f32(uint32_t packed, bool hi) {
+  return hi ? __builtin_amdgcn_cvt_pk_f32_fp8(packed, true)
+            : __builtin_amdgcn_cvt_pk_f32_fp8(packed, false);
+}
+// saturating round-to-nearest-even encode of one value
+__device__ inline uint8_t f32_to_fp8(float v) {
+  if (v != v) return 0x7f;  // NaN stays NaN
+  v = __builtin_fminf(__builtin_fmaxf(v, -448.0f), 448.0f);
+  uint32_t r = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false);
+  return (uint8_t)(r & 0xff);
+}
+
+// ---- wave / block reductions ------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Sum over a block of NW waves; every thread gets the total.  `scratch` holds NW floats.
+template <int NW>
+__device__ inline float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; i++) t += scratch[i];
+  return t;
+}
+
+}  // namespace mi355q

@@ -1,0 +1,446 @@
+// Memory-bound row kernels: RMSNorm family, RoPE, SiLU-mul, KV-cache write, fp8 convert,
+// sampler inner loop.  One workgroup per token row, 16-byte vector accesses where the row
+// allows it, fp32 arithmetic, wave64 shuffles + one LDS hop for the reductions.
+#include "common.h"
+
+namespace mi355q {
+
+template <typename DT>
+__device__ inline float ld(const uint16_t* p, size_t i) { return DT::to_f32(p[i]); }
+
+struct F32 {
+  static constexpr int id = MI355Q_FP32;
+};
+
+// ---------------------------------------------------------------------------
+// RMSNorm
+// ---------------------------------------------------------------------------
+template <typename DT, int NT>
+__global__ __launch_bounds__(NT) void rms_norm_kernel(uint16_t* __restrict__ out,
+                                                      const uint16_t* __restrict__ in,
+                                                      int64_t in_stride,
+                                                      const uint16_t* __restrict__ w, float eps,
+                                                      int H) {
+  __shared__ float scratch[NT / 64];
+  const uint16_t* x = in + (size_t)blockIdx.x * in_stride;
+  uint16_t* y = out + (size_t)blockIdx.x * H;
+  const bool vec = (H % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
+                   (!w || ((uintptr_t)w & 15) == 0);
+  float ss = 0.f;
+  if (vec) {
+    for (int i = threadIdx.x; i < H / 8; i += NT) {
+      const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float a = DT::to_f32((uint16_t)(v[e] & 0xffff)), b = DT::to_f32((uint16_t)(v[e] >> 16));
+        ss += a * a + b * b;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < H; i += NT) {
+      const float a = DT::to_f32(x[i]);
+      ss += a * a;
+    }
+  }
+  const float rs = rsqrtf(block_sum<NT / 64>(ss, scratch) / (float)H + eps);
+  if (vec) {
+    for (int i = threadIdx.x; i < H / 8; i += NT) {
+      const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+      u32x4 wv = u32x4{0, 0, 0, 0};
+      if (w) wv = reinterpret_cast<const u32x4*>(w)[i];
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float a = DT::to_f32((uint16_t)(v[e] & 0xffff)) * rs, b = DT::to_f32((uint16_t)(v[e] >> 16)) * rs;
+        if (w) {
+          a *= DT::to_f32((uint16_t)(wv[e] & 0xffff));
+          b *= DT::to_f32((uint16_t)(wv[e] >> 16));
+        }
+        o[e] = pack2<DT>(a, b);
+      }
+      reinterpret_cast<u32x4*>(y)[i] = o;
+    }
+  } else {
+    for (int i = threadIdx.x; i < H; i += NT) {
+      float a = DT::to_f32(x[i]) * rs;
+      if (w) a *= DT::to_f32(w[i]);
+      y[i] = DT::from_f32(a);
+    }
+  }
+}
+
+// residual = round(x + residual [+ c]); x(out) = round(residual * rs * w).
+// SPLITS > 0 variant: c = round(sum_s partial[s] + bias) takes the place of x and the
+// result goes to `out` (x unused).
+template <typename DT, int NT, bool FROM_PARTIAL>
+__global__ __launch_bounds__(NT) void fused_add_rms_norm_kernel(
+    uint16_t* __restrict__ xio, int64_t x_stride, uint16_t* __restrict__ residual,
+    const float* __restrict__ partial, int splits, size_t split_stride,
+    const uint16_t* __restrict__ bias, const uint16_t* __restrict__ w, float eps, int H) {
+  __shared__ float scratch[NT / 64];
+  uint16_t* x = xio + (size_t)blockIdx.x * x_stride;
+  uint16_t* r = residual + (size_t)blockIdx.x * H;
+  const float* pp = FROM_PARTIAL ? partial + (size_t)blockIdx.x * H : nullptr;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < H; i += NT) {
+    float c;
+    if constexpr (FROM_PARTIAL) {
+      float s = pp[i];
+      for (int k = 1; k < splits; k++) s += pp[(size_t)k * split_stride + i];
+      c = DT::to_f32(DT::from_f32(s));
+      if (bias) c = DT::to_f32(DT::from_f32(c + DT::to_f32(bias[i])));
+    } else {
+      c = DT::to_f32(x[i]);
+    }
+    const uint16_t z = DT::from_f32(c + DT::to_f32(r[i]));
+    r[i] = z;
+    const float zf = DT::to_f32(z);
+    ss += zf * zf;
+  }
+  const float rs = rsqrtf(block_sum<NT / 64>(ss, scratch) / (float)H + eps);
+  for (int i = threadIdx.x; i < H; i += NT) {
+    float a = DT::to_f32(r[i]) * rs;
+    if (w) a *= DT::to_f32(w[i]);
+    x[i] = DT::from_f32(a);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// RoPE (in place)
+// ---------------------------------------------------------------------------
+__device__ inline float load_cache(const void* c, size_t i, int dtype) {
+  if (dtype == MI355Q_FP32) return reinterpret_cast<const float*>(c)[i];
+  const uint16_t h = reinterpret_cast<const uint16_t*>(c)[i];
+  return dtype == MI355Q_BF16 ? BF16::to_f32(h) : FP16::to_f32(h);
+}
+
+template <typename DT>
+__global__ void rotary_kernel(const int64_t* __restrict__ positions, uint16_t* __restrict__ q,
+                              int64_t q_stride, uint16_t* __restrict__ k, int64_t k_stride,
+                              int head, int nh, int nkv, const void* __restrict__ cache, int rot,
+                              int cache_dtype, int is_neox) {
+  const int t = blockIdx.x;
+  const int e = rot / 2;
+  const size_t cbase = (size_t)positions[t] * rot;
+  const int total = (nh + (k ? nkv : 0)) * e;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int h = idx / e, i = idx - h * e;
+    uint16_t* arr = h < nh ? q + (size_t)t * q_stride + (size_t)h * head
+                           : k + (size_t)t * k_stride + (size_t)(h - nh) * head;
+    const int xi = is_neox ? i : 2 * i, yi = is_neox ? e + i : 2 * i + 1;
+    const float c = load_cache(cache, cbase + i, cache_dtype);
+    const float s = load_cache(cache, cbase + e + i, cache_dtype);
+    const float xf = DT::to_f32(arr[xi]), yf = DT::to_f32(arr[yi]);
+    arr[xi] = DT::from_f32(xf * c - yf * s);
+    arr[yi] = DT::from_f32(yf * c + xf * s);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// SiLU-and-mul
+// ---------------------------------------------------------------------------
+template <typename DT>
+__global__ void silu_mul_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ in, int d) {
+  const uint16_t* x = in + (size_t)blockIdx.x * 2 * d;
+  uint16_t* y = out + (size_t)blockIdx.x * d;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    const float g = DT::to_f32(x[i]), u = DT::to_f32(x[d + i]);
+    const float s = DT::to_f32(DT::from_f32(g / (1.0f + __expf(-g))));
+    y[i] = DT::from_f32(s * u);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// KV-cache write
+// ---------------------------------------------------------------------------
+template <typename DT, bool FP8>
+__global__ void reshape_and_cache_kernel(const uint16_t* __restrict__ key,
+                                         const uint16_t* __restrict__ value, int64_t key_stride,
+                                         int64_t value_stride, void* __restrict__ kc,
+                                         void* __restrict__ vc,
+                                         const int64_t* __restrict__ slot_mapping, int kvh,
+                                         int head, int bs, int64_t block_stride,
+                                         const float* __restrict__ k_scale,
+                                         const float* __restrict__ v_scale) {
+  const int64_t slot = slot_mapping[blockIdx.x];
+  if (slot < 0) return;
+  const int64_t b = slot / bs, o = slot % bs;
+  constexpr int X = FP8 ? 16 : 8;
+  const float ks = FP8 ? *k_scale : 1.f, vs = FP8 ? *v_scale : 1.f;
+  for (int idx = threadIdx.x; idx < kvh * head; idx += blockDim.x) {
+    const int h = idx / head, d = idx - h * head;
+    const uint16_t kb = key[(size_t)blockIdx.x * key_stride + idx];
+    const uint16_t vb = value[(size_t)blockIdx.x * value_stride + idx];
+    const size_t ki = (size_t)b * block_stride + (((size_t)h * (head / X) + d / X) * bs + o) * X + d % X;
+    const size_t vi = (size_t)b * block_stride + ((size_t)h * head + d) * bs + o;
+    if constexpr (FP8) {
+      reinterpret_cast<uint8_t*>(kc)[ki] = f32_to_fp8(DT::to_f32(kb) / ks);
+      reinterpret_cast<uint8_t*>(vc)[vi] = f32_to_fp8(DT::to_f32(vb) / vs);
+    } else {
+      reinterpret_cast<uint16_t*>(kc)[ki] = kb;
+      reinterpret_cast<uint16_t*>(vc)[vi] = vb;
+    }
+  }
+}
+
+template <typename DT>
+__global__ void convert_fp8_kernel(void* __restrict__ dst, const void* __restrict__ src, int64_t n,
+                                   float scale, int to_fp8) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (to_fp8) {
+      reinterpret_cast<uint8_t*>(dst)[i] =
+          f32_to_fp8(DT::to_f32(reinterpret_cast<const uint16_t*>(src)[i]) / scale);
+    } else {
+      const uint32_t b = reinterpret_cast<const uint8_t*>(src)[i];
+      const f32x2 f = __builtin_amdgcn_cvt_pk_f32_fp8(b, false);
+      reinterpret_cast<uint16_t*>(dst)[i] = DT::from_f32(f[0] * scale);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Sampler inner loop
+// ---------------------------------------------------------------------------
+template <int DTID>
+__device__ inline float load_logit(const void* p, size_t i) {
+  if constexpr (DTID == MI355Q_FP32) return reinterpret_cast<const float*>(p)[i];
+  else if constexpr (DTID == MI355Q_BF16) return BF16::to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+  else return FP16::to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+}
+
+// first index of the maximum; NaNs are ignored
+template <int DTID>
+__global__ __launch_bounds__(1024) void argmax_kernel(const void* __restrict__ logits,
+                                                      int64_t row_stride, int64_t* __restrict__ ids,
+                                                      int V) {
+  __shared__ float sval[16];
+  __shared__ int sidx[16];
+  const char* row = reinterpret_cast<const char*>(logits) +
+                    (size_t)blockIdx.x * row_stride * (DTID == MI355Q_FP32 ? 4 : 2);
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += 1024) {
+    const float v = load_logit<DTID>(row, i);
+    if (v > best) {  // strided ascending scan keeps the first index per thread
+      best = v;
+      bi = i;
+    }
+  }
+  if (bi == 0x7fffffff && threadIdx.x == 0) bi = 0;  // row of -inf / NaN: index 0
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    sval[wave] = best;
+    sidx[wave] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w2 = 1; w2 < 16; w2++)
+      if (sval[w2] > best || (sval[w2] == best && sidx[w2] < bi)) {
+        best = sval[w2];
+        bi = sidx[w2];
+      }
+    ids[blockIdx.x] = bi == 0x7fffffff ? 0 : bi;
+  }
+}
+
+template <int DTID>
+__global__ void repetition_penalty_kernel(void* __restrict__ logits,
+                                          const uint8_t* __restrict__ pm,
+                                          const uint8_t* __restrict__ om,
+                                          const void* __restrict__ pen, int V) {
+  const int b = blockIdx.y;
+  const float p = load_logit<DTID>(pen, b);
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x) {
+    const size_t o = (size_t)b * V + v;
+    if (pm[o] || om[o]) {
+      float l = load_logit<DTID>(logits, o);
+      l = l > 0.f ? l / p : l * p;
+      if constexpr (DTID == MI355Q_FP32) reinterpret_cast<float*>(logits)[o] = l;
+      else if constexpr (DTID == MI355Q_BF16) reinterpret_cast<uint16_t*>(logits)[o] = BF16::from_f32(l);
+      else reinterpret_cast<uint16_t*>(logits)[o] = FP16::from_f32(l);
+    }
+  }
+}
+
+static int check_h16(int dtype, const char* what) {
+  MI355Q_REQUIRE(dtype == MI355Q_BF16 || dtype == MI355Q_FP16, "%s: dtype must be bf16 or fp16", what);
+  return 0;
+}
+
+}  // namespace mi355q
+
+using namespace mi355q;
+
+#define DISPATCH_H16(dtype, ...)            \
+  if ((dtype) == MI355Q_BF16) {             \
+    using DT = BF16;                        \
+    __VA_ARGS__;                            \
+  } else {                                  \
+    using DT = FP16;                        \
+    __VA_ARGS__;                            \
+  }
+
+extern "C" int mi355q_rms_norm(void* out, const void* input, int64_t input_stride,
+                               const void* weight, float epsilon, int num_tokens, int hidden,
+                               int dtype, mi355q_stream_t stream) {
+  if (int e = check_h16(dtype, "rms_norm")) return e;
+  if (num_tokens == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(out && input && hidden > 0 && num_tokens >= 0, "rms_norm: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (num_tokens < 256) {
+    DISPATCH_H16(dtype, hipLaunchKernelGGL((rms_norm_kernel<DT, 1024>), dim3(num_tokens), dim3(1024), 0, s,
+                                           (uint16_t*)out, (const uint16_t*)input, input_stride,
+                                           (const uint16_t*)weight, epsilon, hidden));
+  } else {
+    DISPATCH_H16(dtype, hipLaunchKernelGGL((rms_norm_kernel<DT, 256>), dim3(num_tokens), dim3(256), 0, s,
+                                           (uint16_t*)out, (const uint16_t*)input, input_stride,
+                                           (const uint16_t*)weight, epsilon, hidden));
+  }
+  return check_launch("rms_norm_kernel");
+}
+
+extern "C" int mi355q_fused_add_rms_norm(void* input, int64_t input_stride, void* residual,
+                                         const void* weight, float epsilon, int num_tokens,
+                                         int hidden, int dtype, mi355q_stream_t stream) {
+  if (int e = check_h16(dtype, "fused_add_rms_norm")) return e;
+  if (num_tokens == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(input && residual && hidden > 0 && num_tokens >= 0, "fused_add_rms_norm: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_H16(dtype, hipLaunchKernelGGL((fused_add_rms_norm_kernel<DT, 1024, false>), dim3(num_tokens),
+                                         dim3(1024), 0, s, (uint16_t*)input, input_stride,
+                                         (uint16_t*)residual, (const float*)nullptr, 0, (size_t)0,
+                                         (const uint16_t*)nullptr, (const uint16_t*)weight, epsilon, hidden));
+  return check_launch("fused_add_rms_norm_kernel");
+}
+
+extern "C" int mi355q_splitk_add_rms_norm(void* out, void* residual, const float* partial,
+                                          int splits, const void* bias, const void* weight,
+                                          float epsilon, int num_tokens, int hidden, int dtype,
+                                          mi355q_stream_t stream) {
+  if (int e = check_h16(dtype, "splitk_add_rms_norm")) return e;
+  if (num_tokens == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(out && residual && partial && splits >= 1 && hidden > 0 && num_tokens >= 0,
+                 "splitk_add_rms_norm: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_H16(dtype, hipLaunchKernelGGL((fused_add_rms_norm_kernel<DT, 1024, true>), dim3(num_tokens),
+                                         dim3(1024), 0, s, (uint16_t*)out, (int64_t)hidden,
+                                         (uint16_t*)residual, partial, splits,
+                                         (size_t)num_tokens * hidden, (const uint16_t*)bias,
+                                         (const uint16_t*)weight, epsilon, hidden));
+  return check_launch("splitk_add_rms_norm_kernel");
+}
+
+extern "C" int mi355q_rotary_embedding(const int64_t* positions, void* query, int64_t query_stride,
+                                       void* key, int64_t key_stride, int head_size, int num_heads,
+                                       int num_kv_heads, const void* cos_sin_cache, int rot_dim,
+                                       int cache_dtype, int is_neox, int num_tokens, int dtype,
+                                       mi355q_stream_t stream) {
+  if (int e = check_h16(dtype, "rotary_embedding")) return e;
+  if (num_tokens == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(positions && query && cos_sin_cache, "rotary_embedding: null pointer");
+  MI355Q_REQUIRE(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "rotary_embedding: rot_dim %d vs head_size %d", rot_dim, head_size);
+  MI355Q_REQUIRE(cache_dtype >= MI355Q_BF16 && cache_dtype <= MI355Q_FP32, "rotary_embedding: bad cache dtype");
+  if (num_tokens == 0) return MI355Q_OK;
+  int threads = num_heads * rot_dim / 2;
+  threads = threads < 64 ? 64 : (threads > 512 ? 512 : (threads + 63) / 64 * 64);
+  DISPATCH_H16(dtype, hipLaunchKernelGGL((rotary_kernel<DT>), dim3(num_tokens), dim3(threads), 0,
+                                         (hipStream_t)stream, positions, (uint16_t*)query, query_stride,
+                                         (uint16_t*)key, key_stride, head_size, num_heads, num_kv_heads,
+                                         cos_sin_cache, rot_dim, cache_dtype, is_neox));
+  return check_launch("rotary_kernel");
+}
+
+extern "C" int mi355q_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dtype,
+                                   mi355q_stream_t stream) {
+  if (int e = check_h16(dtype, "silu_and_mul")) return e;
+  if (num_tokens == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(out && input && d > 0, "silu_and_mul: bad arguments");
+  DISPATCH_H16(dtype, hipLaunchKernelGGL((silu_mul_kernel<DT>), dim3(num_tokens), dim3(d < 1024 ? (d + 63) / 64 * 64 : 1024),
+                                         0, (hipStream_t)stream, (uint16_t*)out, (const uint16_t*)input, d));
+  return check_launch("silu_mul_kernel");
+}
+
+extern "C" int mi355q_reshape_and_cache(const void* key, const void* value, int64_t key_stride,
+                                        int64_t value_stride, void* key_cache, void* value_cache,
+                                        const int64_t* slot_mapping, int num_tokens,
+                                        int num_kv_heads, int head_size, int block_size,
+                                        int64_t block_stride, int dtype, int kv_fp8,
+                                        const float* k_scale, const float* v_scale,
+                                        mi355q_stream_t stream) {
+  if (int e = check_h16(dtype, "reshape_and_cache")) return e;
+  if (num_tokens == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(key && value && key_cache && value_cache && slot_mapping, "reshape_and_cache: null pointer");
+  MI355Q_REQUIRE(head_size % (kv_fp8 ? 16 : 8) == 0, "reshape_and_cache: head_size %d", head_size);
+  if (kv_fp8) MI355Q_REQUIRE(k_scale && v_scale, "reshape_and_cache: fp8 cache needs k_scale/v_scale");
+  if (num_tokens == 0) return MI355Q_OK;
+  int threads = num_kv_heads * head_size;
+  threads = threads > 512 ? 512 : (threads + 63) / 64 * 64;
+  hipStream_t s = (hipStream_t)stream;
+  if (kv_fp8) {
+    DISPATCH_H16(dtype, hipLaunchKernelGGL((reshape_and_cache_kernel<DT, true>), dim3(num_tokens), dim3(threads), 0, s,
+                                           (const uint16_t*)key, (const uint16_t*)value, key_stride, value_stride,
+                                           key_cache, value_cache, slot_mapping, num_kv_heads, head_size,
+                                           block_size, block_stride, k_scale, v_scale));
+  } else {
+    DISPATCH_H16(dtype, hipLaunchKernelGGL((reshape_and_cache_kernel<DT, false>), dim3(num_tokens), dim3(threads), 0, s,
+                                           (const uint16_t*)key, (const uint16_t*)value, key_stride, value_stride,
+                                           key_cache, value_cache, slot_mapping, num_kv_heads, head_size,
+                                           block_size, block_stride, k_scale, v_scale));
+  }
+  return check_launch("reshape_and_cache_kernel");
+}
+
+extern "C" int mi355q_convert_fp8(void* dst, const void* src, int64_t n, float scale, int dtype,
+                                  int to_fp8, mi355q_stream_t stream) {
+  if (int e = check_h16(dtype, "convert_fp8")) return e;
+  MI355Q_REQUIRE(dst && src && n >= 0, "convert_fp8: bad arguments");
+  if (n == 0) return MI355Q_OK;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  DISPATCH_H16(dtype, hipLaunchKernelGGL((convert_fp8_kernel<DT>), dim3(grid), dim3(256), 0,
+                                         (hipStream_t)stream, dst, src, n, scale, to_fp8));
+  return check_launch("convert_fp8_kernel");
+}
+
+extern "C" int mi355q_argmax(const void* logits, int64_t row_stride, int64_t* ids, int num_rows,
+                             int vocab, int dtype, mi355q_stream_t stream) {
+  if (num_rows == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(logits && ids && vocab > 0, "argmax: bad arguments");
+  MI355Q_REQUIRE(dtype >= MI355Q_BF16 && dtype <= MI355Q_FP32, "argmax: bad dtype");
+  if (num_rows == 0) return MI355Q_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MI355Q_FP32)
+    hipLaunchKernelGGL((argmax_kernel<MI355Q_FP32>), dim3(num_rows), dim3(1024), 0, s, logits, row_stride, ids, vocab);
+  else if (dtype == MI355Q_BF16)
+    hipLaunchKernelGGL((argmax_kernel<MI355Q_BF16>), dim3(num_rows), dim3(1024), 0, s, logits, row_stride, ids, vocab);
+  else
+    hipLaunchKernelGGL((argmax_kernel<MI355Q_FP16>), dim3(num_rows), dim3(1024), 0, s, logits, row_stride, ids, vocab);
+  return check_launch("argmax_kernel");
+}
+
+extern "C" int mi355q_apply_repetition_penalties(void* logits, const uint8_t* prompt_mask,
+                                                 const uint8_t* output_mask, const void* penalties,
+                                                 int num_seqs, int vocab, int dtype,
+                                                 mi355q_stream_t stream) {
+  MI355Q_REQUIRE(logits && prompt_mask && output_mask && penalties && vocab > 0, "apply_repetition_penalties: bad arguments");
+  MI355Q_REQUIRE(dtype >= MI355Q_BF16 && dtype <= MI355Q_FP32, "apply_repetition_penalties: bad dtype");
+  if (num_seqs == 0) return MI355Q_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((vocab + 1023) / 1024 < 64 ? (vocab + 1023) / 1024 : 64, num_seqs);
+  if (dtype == MI355Q_FP32)
+    hipLaunchKernelGGL((repetition_penalty_kernel<MI355Q_FP32>), grid, dim3(1024), 0, s, logits, prompt_mask, output_mask, penalties, vocab);
+  else if (dtype == MI355Q_BF16)
+    hipLaunchKernelGGL((repetition_penalty_kernel<MI355Q_BF16>), grid, dim3(1024), 0, s, logits, prompt_mask, output_mask, penalties, vocab);
+  else
+    hipLaunchKernelGGL((repetition_penalty_kernel<MI355Q_FP16>), grid, dim3(1024), 0, s, logits, prompt_mask, output_mask, penalties, vocab);
+  return check_launch("repetition_penalty_kernel");
+}

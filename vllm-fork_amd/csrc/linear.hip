@@ -1,0 +1,128 @@
+// Unquantized skinny linear for decode: C[M,N] = A[M,K] * W[N,K]^T with M small
+// (lm_head, and the 16-bit comparator of the W4A16 path).  HBM-bound on W: every wave
+// streams whole weight rows with 16-byte lane loads (1 KiB contiguous per wave
+// instruction), the activations sit in LDS, products run on v_dot2_f32 with fp32
+// accumulation, and a wave64 shuffle tree finishes each row.
+#include "common.h"
+
+namespace mi355q {
+
+template <typename DT>
+__device__ inline float dot2(uint32_t a, uint32_t b, float c);
+template <>
+__device__ inline float dot2<BF16>(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+template <>
+__device__ inline float dot2<FP16>(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
+}
+
+// MB = activation rows handled per pass (1, 2, 4, 8); R = weight rows per wave iteration.
+template <typename DT, int MB>
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const uint16_t* __restrict__ a, int lda,
+                                                            const uint16_t* __restrict__ w,
+                                                            const uint16_t* __restrict__ bias,
+                                                            uint16_t* __restrict__ c, int M, int N,
+                                                            int K, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* xs = reinterpret_cast<u32x4*>(smem);  // [MB][K/8]
+  constexpr int R = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * MB;
+  const int mb = min(MB, M - m0);
+  const int kv = K >> 3;  // 16-byte vectors per row
+
+  for (int idx = threadIdx.x; idx < MB * kv; idx += 256) {
+    const int m = idx / kv, v = idx - m * kv;
+    const int mr = m0 + min(m, mb - 1);
+    xs[idx] = reinterpret_cast<const u32x4*>(a + (size_t)mr * lda)[v];
+  }
+  __syncthreads();
+
+  const int n_begin = blockIdx.x * rows_per_block;
+  const int n_end = min(N, n_begin + rows_per_block);
+  for (int n = n_begin + wave * R; n < n_end; n += 4 * R) {
+    float acc[R][MB];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int m = 0; m < MB; m++) acc[r][m] = 0.f;
+    const u32x4* w0 = reinterpret_cast<const u32x4*>(w + (size_t)n * K);
+    const bool has1 = n + 1 < n_end;
+    const u32x4* w1 = reinterpret_cast<const u32x4*>(w + (size_t)(has1 ? n + 1 : n) * K);
+#pragma unroll 4
+    for (int v = lane; v < kv; v += 64) {
+      const u32x4 wa = __builtin_nontemporal_load(w0 + v);
+      const u32x4 wb = __builtin_nontemporal_load(w1 + v);
+#pragma unroll
+      for (int m = 0; m < MB; m++) {
+        const u32x4 x = xs[m * kv + v];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          acc[0][m] = dot2<DT>(wa[e], x[e], acc[0][m]);
+          acc[1][m] = dot2<DT>(wb[e], x[e], acc[1][m]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int m = 0; m < MB; m++) acc[r][m] = wave_sum(acc[r][m]);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (r == 1 && !has1) break;
+        const float b = bias ? DT::to_f32(bias[n + r]) : 0.f;
+#pragma unroll
+        for (int m = 0; m < MB; m++)
+          if (m < mb)
+            c[(size_t)(m0 + m) * N + n + r] =
+                bias ? DT::from_f32(DT::to_f32(DT::from_f32(acc[r][m])) + b) : DT::from_f32(acc[r][m]);
+      }
+    }
+  }
+}
+
+template <typename DT>
+static int launch_linear(const void* a, int lda, const void* w, const void* bias, void* c, int M,
+                         int N, int K, hipStream_t stream) {
+  // rows of A per pass: bounded by 64 KiB of LDS for the staged activations
+  int MB = M >= 8 ? 8 : (M >= 4 ? 4 : (M >= 2 ? 2 : 1));
+  while (MB > 1 && (size_t)MB * K * 2 > 64 * 1024) MB >>= 1;
+  const size_t lds = (size_t)MB * K * 2;
+  MI355Q_REQUIRE(lds <= 64 * 1024, "linear_skinny: K=%d too large for one LDS pass", K);
+  // enough blocks to fill the chip a few times over, each amortising its activation staging
+  int rows_per_block = 64;
+  while (rows_per_block > 8 && (N + rows_per_block - 1) / rows_per_block < 2048) rows_per_block >>= 1;
+  dim3 grid((N + rows_per_block - 1) / rows_per_block, (M + MB - 1) / MB), block(256);
+#define MI355Q_LL(mb)                                                                            \
+  hipLaunchKernelGGL((linear_skinny_kernel<DT, mb>), grid, block, lds, stream, (const uint16_t*)a, \
+                     lda, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)c, M, N, K,      \
+                     rows_per_block)
+  switch (MB) {
+    case 8: MI355Q_LL(8); break;
+    case 4: MI355Q_LL(4); break;
+    case 2: MI355Q_LL(2); break;
+    default: MI355Q_LL(1); break;
+  }
+#undef MI355Q_LL
+  return check_launch("linear_skinny_kernel");
+}
+
+}  // namespace mi355q
+
+using namespace mi355q;
+
+extern "C" int mi355q_linear_skinny(const void* a, int lda, const void* w, const void* bias,
+                                    void* c, int M, int N, int K, int act_dtype,
+                                    mi355q_stream_t stream) {
+  MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "linear_skinny: dtype must be bf16 or fp16");
+  if (M == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(a && w && c && N > 0 && K > 0 && M >= 0, "linear_skinny: bad arguments");
+  MI355Q_REQUIRE(K % 8 == 0 && lda % 8 == 0 && lda >= K, "linear_skinny: K=%d and lda=%d must be multiples of 8", K, lda);
+  MI355Q_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, "linear_skinny: pointers must be 16-byte aligned");
+  if (act_dtype == MI355Q_BF16) return launch_linear<BF16>(a, lda, w, bias, c, M, N, K, (hipStream_t)stream);
+  return launch_linear<FP16>(a, lda, w, bias, c, M, N, K, (hipStream_t)stream);
+}

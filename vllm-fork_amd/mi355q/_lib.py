@@ -1,0 +1,86 @@
+"""ctypes binding of libmi355q.so (the C ABI declared in include/mi355q.h).
+
+The library is loaded from mi355q/lib/ inside the source tree.  There is no CPU
+fallback: if the shared object is missing, import of the ops raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355q.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "mi355q.h"))
+
+OK, EINVAL, ENOSPACE, EHIP = 0, -1, -2, -3
+BF16, FP16, FP32 = 0, 1, 2
+W_GPTQ, W_NSEQ, W_AWQ = 0, 1, 2
+ZP_CONST, ZP_NSEQ, ZP_AWQ, ZP_GPTQ_V1 = 0, 1, 2, 3
+PA_PARTITION = 256
+
+_lib = None
+
+c_int, c_i64, c_f32, c_sz, c_vp = (ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t,
+                                    ctypes.c_void_p)
+
+# argtypes of every entry point, in header order
+_SIGS = {
+    "mi355q_last_error": (ctypes.c_char_p, []),
+    "mi355q_version": (c_int, []),
+    "mi355q_w4a16_repack": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_w4a16_repack_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mi355q_w4a16_unpack_host": (c_int, [c_vp, c_vp, c_int, c_int]),
+    "mi355q_w4a16_packed_bytes": (c_sz, [c_int, c_int]),
+    "mi355q_w4a16_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "mi355q_w4a16_gemm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                  c_int, c_vp, c_sz, c_int, c_vp]),
+    "mi355q_w4a16_gemm_silu_mul": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int,
+                                           c_int, c_int, c_vp, c_sz, c_int, c_vp]),
+    "mi355q_w4a16_dequantize": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_linear_skinny": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_rms_norm": (c_int, [c_vp, c_vp, c_i64, c_vp, c_f32, c_int, c_int, c_int, c_vp]),
+    "mi355q_fused_add_rms_norm": (c_int, [c_vp, c_i64, c_vp, c_vp, c_f32, c_int, c_int, c_int, c_vp]),
+    "mi355q_splitk_add_rms_norm": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_f32, c_int, c_int, c_int, c_vp]),
+    "mi355q_rotary_embedding": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_int,
+                                        c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_silu_and_mul": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "mi355q_reshape_and_cache": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int,
+                                         c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    "mi355q_convert_fp8": (c_int, [c_vp, c_vp, c_i64, c_f32, c_int, c_int, c_vp]),
+    "mi355q_paged_attention": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_int,
+                                       c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_int,
+                                       c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "mi355q_paged_prefill_attention": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64,
+                                               c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_vp,
+                                               c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "mi355q_argmax": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_vp]),
+    "mi355q_apply_repetition_penalties": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+}
+
+
+def declared_symbols():
+    """Names of the entry points declared in include/mi355q.h."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(mi355q_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C vllm-fork_amd/csrc` "
+                "(there is no CPU fallback for the MI355X kernels)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != OK:
+        msg = lib().mi355q_last_error().decode()
+        raise RuntimeError(f"mi355q error {status}: {msg}")

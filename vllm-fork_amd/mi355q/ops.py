@@ -1,0 +1,316 @@
+"""Tensor-level ops of the MI355X quantized-decode path.
+
+Function names, argument order and in-place/functional behaviour follow
+vllm/_custom_ops.py of the reference fork (cited per function), so call sites in
+the fork can be pointed here unchanged.  Every op launches on torch's current
+stream and never synchronises; outputs come from torch's caching allocator, so
+the ops are HIP-graph capturable.  All arithmetic runs in libmi355q.so; there is
+no eager/CPU fallback.
+"""
+import torch
+
+from . import _lib
+from ._lib import BF16, FP16, FP32, check
+
+_DT = {torch.bfloat16: BF16, torch.float16: FP16, torch.float32: FP32}
+
+
+def _dt(t: torch.Tensor, allow_fp32: bool = False) -> int:
+    if t.dtype not in _DT or (t.dtype == torch.float32 and not allow_fp32):
+        raise RuntimeError(f"unsupported dtype {t.dtype}")
+    return _DT[t.dtype]
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mi355q ops need device tensors (MI355X); no CPU fallback exists")
+
+
+# ---------------------------------------------------------------------------
+# W4A16
+# ---------------------------------------------------------------------------
+class PackedW4:
+    """Kernel-layout 4-bit weight of one linear layer (output of `w4a16_repack`)."""
+
+    __slots__ = ("packed", "scales", "zc", "K", "N", "G")
+
+    def __init__(self, packed, scales, zc, K, N, G):
+        self.packed, self.scales, self.zc, self.K, self.N, self.G = packed, scales, zc, K, N, G
+
+
+def w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor | None,
+                 group_size: int, src_layout: int = _lib.W_GPTQ, zp_mode: int = _lib.ZP_CONST) -> PackedW4:
+    """Checkpoint tensors -> kernel layout.  Stands in for
+    MPLinearKernel.process_weights_after_loading (mixed_precision/triton_w4a16.py:338-426).
+    Works on device tensors (HIP kernel) and on CPU tensors (host arithmetic, for load
+    paths that repack before upload)."""
+    if src_layout == _lib.W_GPTQ:
+        K, N = qweight.shape[0] * 8, qweight.shape[1]
+    else:
+        K, N = qweight.shape[0], qweight.shape[1] * 8
+    G = K if group_size in (-1, 0) else group_size
+    if scales.shape != (K // G, N):
+        raise RuntimeError(f"scales shape {tuple(scales.shape)} != ({K // G}, {N})")
+    if qweight.dtype != torch.int32 or not qweight.is_contiguous():
+        raise RuntimeError("qweight must be a contiguous int32 tensor")
+    act = _dt(scales)
+    packed = torch.empty(K * N // 8, dtype=torch.int32, device=qweight.device)
+    zc = None
+    if zp_mode != _lib.ZP_CONST:
+        if qzeros is None or qzeros.shape != (K // G, N // 8) or qzeros.dtype != torch.int32:
+            raise RuntimeError("qzeros must be int32 [K/G, N/8] for asymmetric formats")
+        qzeros = qzeros.contiguous()
+        zc = torch.empty((K // G, N), dtype=scales.dtype, device=qweight.device)
+    L = _lib.lib()
+    if qweight.is_cuda:
+        check(L.mi355q_w4a16_repack(qweight.data_ptr(), _ptr(qzeros if zc is not None else None),
+                                    packed.data_ptr(), _ptr(zc), K, N, G, src_layout, zp_mode, act, _stream()))
+    else:
+        check(L.mi355q_w4a16_repack_host(qweight.data_ptr(), _ptr(qzeros if zc is not None else None),
+                                         packed.data_ptr(), _ptr(zc), K, N, G, src_layout, zp_mode, act))
+    return PackedW4(packed, scales.contiguous(), zc, K, N, G)
+
+
+_WS: dict = {}
+
+
+def _workspace(dev, nbytes: int) -> torch.Tensor:
+    """Per-device split-K workspace, grown on demand (outside graph capture) and then
+    reused; under capture the pointer is therefore stable."""
+    ws = _WS.get(dev)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 24), dtype=torch.uint8, device=dev)
+        _WS[dev] = ws
+    return ws
+
+
+def w4a16_gemm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, split_k: int = 0,
+               fuse_silu_mul: bool = False) -> torch.Tensor:
+    """x[..., K] @ dequant(w)[K, N] (+ bias).  Stands in for ops.gptq_gemm
+    (vllm/_custom_ops.py:558-577), ops.awq_gemm (:525-536) and triton_w4a16_gemm
+    (mixed_precision/triton_w4a16.py:164-270).  With fuse_silu_mul, x is the
+    [..., 2K] gate_up output and SiluAndMul is applied on the fly."""
+    _need_cuda(x, w.packed)
+    Kx = w.K * (2 if fuse_silu_mul else 1)
+    if x.shape[-1] != Kx:
+        raise RuntimeError(f"input feature size {x.shape[-1]} != {Kx}")
+    if x.dtype != w.scales.dtype:
+        raise RuntimeError(f"activation dtype {x.dtype} != scales dtype {w.scales.dtype}")
+    x2 = x.reshape(-1, Kx)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    out = torch.empty((M, w.N), dtype=x.dtype, device=x.device)
+    L = _lib.lib()
+    ws_bytes = L.mi355q_w4a16_workspace_bytes(M, w.N, w.K, w.G)
+    ws = _workspace(x.device, ws_bytes)
+    fn = L.mi355q_w4a16_gemm_silu_mul if fuse_silu_mul else L.mi355q_w4a16_gemm
+    check(fn(x2.data_ptr(), x2.stride(0), w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc), _ptr(bias),
+             out.data_ptr(), M, w.N, w.K, w.G, _dt(x), ws.data_ptr(), ws.numel(), split_k, _stream()))
+    return out.reshape(x.shape[:-1] + (w.N,))
+
+
+def w4a16_dequantize(w: PackedW4) -> torch.Tensor:
+    """[K, N] dequantised weight.  Stands in for ops.awq_dequantize (vllm/_custom_ops.py:491-505)."""
+    _need_cuda(w.packed)
+    out = torch.empty((w.K, w.N), dtype=w.scales.dtype, device=w.packed.device)
+    check(_lib.lib().mi355q_w4a16_dequantize(w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc),
+                                             out.data_ptr(), w.K, w.N, w.G, _dt(w.scales), _stream()))
+    return out
+
+
+def gptq_gemm(a, b_q_weight: PackedW4, b_gptq_qzeros, b_gptq_scales, b_g_idx, use_exllama: bool,
+              use_v2_format: bool, bit: int) -> torch.Tensor:
+    """Signature of ops.gptq_gemm (vllm/_custom_ops.py:558-577).  b_q_weight is the
+    repacked weight (the reference passes the gptq_shuffle'd tensor here); zeros and scales
+    travel inside it, g_idx must be empty (act-order is not supported yet)."""
+    if bit != 4:
+        raise RuntimeError(f"gptq_gemm: {bit}-bit weights are not supported")
+    if b_g_idx is not None and b_g_idx.numel() > 0:
+        raise RuntimeError("gptq_gemm: act-order (g_idx) is not supported")
+    return w4a16_gemm(a, b_q_weight)
+
+
+def awq_gemm(input, qweight: PackedW4, scales, qzeros, split_k_iters: int) -> torch.Tensor:
+    """Signature of ops.awq_gemm (vllm/_custom_ops.py:525-536); split_k_iters is accepted
+    and ignored (the kernel chooses its own deterministic split)."""
+    return w4a16_gemm(input, qweight)
+
+
+def awq_dequantize(qweight: PackedW4, scales, zeros, split_k_iters: int, thx: int, thy: int) -> torch.Tensor:
+    """Signature of ops.awq_dequantize (vllm/_custom_ops.py:491-505)."""
+    return w4a16_dequantize(qweight)
+
+
+def linear_skinny(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """x[..., K] @ weight[N, K]^T (+ bias) for small token counts.  Stands in for
+    ops.wvSplitK / ops.LLMM1 (vllm/_custom_ops.py:2161-2213) as used by
+    rocm_unquantized_gemm (vllm/model_executor/layers/utils.py:116-186)."""
+    _need_cuda(x, weight)
+    N, K = weight.shape
+    x2 = x.reshape(-1, K)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(_lib.lib().mi355q_linear_skinny(x2.data_ptr(), x2.stride(0), weight.data_ptr(), _ptr(bias),
+                                          out.data_ptr(), M, N, K, _dt(x), _stream()))
+    return out.reshape(x.shape[:-1] + (N,))
+
+
+# ---------------------------------------------------------------------------
+# norms / rope / activation
+# ---------------------------------------------------------------------------
+def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor | None, epsilon: float) -> None:
+    """ops.rms_norm (vllm/_custom_ops.py:229-235)."""
+    _need_cuda(out, input)
+    H = input.shape[-1]
+    x2 = input.reshape(-1, H) if input.is_contiguous() else input
+    if x2.dim() != 2 or x2.stride(-1) != 1:
+        raise RuntimeError("rms_norm: input must be [tokens, hidden] with a contiguous last dim")
+    check(_lib.lib().mi355q_rms_norm(out.data_ptr(), x2.data_ptr(), x2.stride(0), _ptr(weight), epsilon,
+                                     x2.shape[0], H, _dt(input), _stream()))
+
+
+def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor | None,
+                       epsilon: float) -> None:
+    """ops.fused_add_rms_norm (vllm/_custom_ops.py:269-276): in place on both tensors."""
+    _need_cuda(input, residual)
+    H = input.shape[-1]
+    x2 = input.view(-1, H)
+    if not residual.is_contiguous():
+        raise RuntimeError("fused_add_rms_norm: residual must be contiguous")
+    check(_lib.lib().mi355q_fused_add_rms_norm(x2.data_ptr(), x2.stride(0), residual.data_ptr(), _ptr(weight),
+                                               epsilon, x2.shape[0], H, _dt(input), _stream()))
+
+
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor | None, head_size: int,
+                     cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+    """ops.rotary_embedding (vllm/_custom_ops.py:201-225): in place on query and key."""
+    _need_cuda(positions, query, cos_sin_cache)
+    T = positions.numel()
+    if positions.dtype != torch.int64:
+        raise RuntimeError("rotary_embedding: positions must be int64")
+    q2 = query.view(T, -1)
+    nh = q2.shape[1] // head_size
+    k2 = None if key is None else key.view(T, -1)
+    nkv = 0 if k2 is None else k2.shape[1] // head_size
+    check(_lib.lib().mi355q_rotary_embedding(
+        positions.data_ptr(), q2.data_ptr(), q2.stride(0), _ptr(k2), 0 if k2 is None else k2.stride(0),
+        head_size, nh, nkv, cos_sin_cache.data_ptr(), cos_sin_cache.shape[1], _dt(cos_sin_cache, True),
+        int(is_neox), T, _dt(query), _stream()))
+
+
+def silu_and_mul(out: torch.Tensor, input: torch.Tensor) -> None:
+    """torch.ops._C.silu_and_mul(out, input) (csrc/libtorch_stable/activation_kernels.cu:98-155)."""
+    _need_cuda(out, input)
+    d = input.shape[-1] // 2
+    if not input.is_contiguous() or not out.is_contiguous():
+        raise RuntimeError("silu_and_mul: tensors must be contiguous")
+    check(_lib.lib().mi355q_silu_and_mul(out.data_ptr(), input.data_ptr(), input.numel() // (2 * d), d,
+                                         _dt(input), _stream()))
+
+
+# ---------------------------------------------------------------------------
+# KV cache + attention
+# ---------------------------------------------------------------------------
+def _is_fp8(kv_cache_dtype: str) -> bool:
+    if kv_cache_dtype in ("auto", "bfloat16", "float16", "half"):
+        return False
+    if kv_cache_dtype in ("fp8", "fp8_e4m3"):
+        return True
+    raise RuntimeError(f"unsupported kv_cache_dtype {kv_cache_dtype!r}")
+
+
+def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype: str, k_scale, v_scale) -> None:
+    """ops.reshape_and_cache (vllm/_custom_ops.py:2592-2611).  key/value [T, kv_heads, head];
+    key_cache [blocks, kv_heads, head/x, block_size, x]; value_cache [blocks, kv_heads, head, block_size]."""
+    _need_cuda(key, value, key_cache, value_cache, slot_mapping)
+    T, kvh, head = key.shape
+    bs = value_cache.shape[3]
+    if slot_mapping.dtype != torch.int64:
+        raise RuntimeError("reshape_and_cache: slot_mapping must be int64")
+    check(_lib.lib().mi355q_reshape_and_cache(
+        key.data_ptr(), value.data_ptr(), key.stride(0), value.stride(0), key_cache.data_ptr(),
+        value_cache.data_ptr(), slot_mapping.data_ptr(), slot_mapping.numel(), kvh, head, bs, key_cache.stride(0),
+        _dt(key), int(_is_fp8(kv_cache_dtype)), _ptr(k_scale), _ptr(v_scale), _stream()))
+
+
+def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0, kv_dtype: str = "fp8") -> None:
+    """ops.convert_fp8 (vllm/_custom_ops.py:2908): fp8 cache <-> 16-bit tensor."""
+    _need_cuda(output, input)
+    to_fp8 = output.element_size() == 1
+    ref = input if to_fp8 else output
+    check(_lib.lib().mi355q_convert_fp8(output.data_ptr(), input.data_ptr(), input.numel(), scale, _dt(ref),
+                                        int(to_fp8), _stream()))
+
+
+def paged_attention_rocm(out, exp_sum, max_logits, tmp_out, query, key_cache, value_cache, num_kv_heads: int,
+                         scale: float, block_tables, seq_lens, query_start_loc, block_size: int, max_seq_len: int,
+                         alibi_slopes, kv_cache_dtype: str, k_scale, v_scale, fp8_out_scale=None,
+                         mfma_type: str = "f16") -> None:
+    """ops.paged_attention_rocm (vllm/_custom_ops.py:120-163), decode rows only."""
+    _need_cuda(out, query, key_cache, value_cache, block_tables, seq_lens)
+    if fp8_out_scale is not None:
+        raise RuntimeError("paged_attention_rocm: fp8 output is not supported")
+    if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise RuntimeError("paged_attention_rocm: block_tables and seq_lens must be int32")
+    S = block_tables.shape[0]
+    H, D = query.shape[1], query.shape[2]
+    check(_lib.lib().mi355q_paged_attention(
+        out.data_ptr(), _ptr(exp_sum), _ptr(max_logits), _ptr(tmp_out), query.data_ptr(), query.stride(0),
+        key_cache.data_ptr(), value_cache.data_ptr(), key_cache.stride(0), key_cache.stride(1), S, H,
+        num_kv_heads, D, scale, block_tables.data_ptr(), block_tables.shape[1], seq_lens.data_ptr(),
+        _ptr(query_start_loc), block_size, max_seq_len, _ptr(alibi_slopes), _dt(query),
+        int(_is_fp8(kv_cache_dtype)), _ptr(k_scale), _ptr(v_scale), _stream()))
+
+
+def paged_prefill_attention(out, exp_sum, max_logits, tmp_out, query, key_cache, value_cache, num_kv_heads: int,
+                            scale: float, block_tables, seq_lens, query_start_loc, max_query_len: int,
+                            block_size: int, max_seq_len: int, alibi_slopes, kv_cache_dtype: str, k_scale,
+                            v_scale) -> None:
+    """Causal attention for rows of any query length, K/V read from the paged cache
+    (the prompt rows of chunked_prefill_paged_decode.py:303-326)."""
+    _need_cuda(out, query, key_cache, value_cache, block_tables, seq_lens, query_start_loc)
+    S = block_tables.shape[0]
+    H, D = query.shape[1], query.shape[2]
+    check(_lib.lib().mi355q_paged_prefill_attention(
+        out.data_ptr(), _ptr(exp_sum), _ptr(max_logits), _ptr(tmp_out), query.data_ptr(), query.stride(0),
+        key_cache.data_ptr(), value_cache.data_ptr(), key_cache.stride(0), key_cache.stride(1), S, H,
+        num_kv_heads, D, scale, block_tables.data_ptr(), block_tables.shape[1], seq_lens.data_ptr(),
+        query_start_loc.data_ptr(), max_query_len, block_size, max_seq_len, _ptr(alibi_slopes), _dt(query),
+        int(_is_fp8(kv_cache_dtype)), _ptr(k_scale), _ptr(v_scale), _stream()))
+
+
+# ---------------------------------------------------------------------------
+# sampler inner loop
+# ---------------------------------------------------------------------------
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    """logits.float().argmax(-1) with first-index ties (vllm/v1/sample/sampler.py:96,240-241)."""
+    _need_cuda(logits)
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("argmax: logits must be [rows, vocab] with a contiguous last dim")
+    ids = torch.empty((logits.shape[0],), dtype=torch.int64, device=logits.device)
+    check(_lib.lib().mi355q_argmax(logits.data_ptr(), logits.stride(0), ids.data_ptr(), logits.shape[0],
+                                   logits.shape[1], _dt(logits, True), _stream()))
+    return ids
+
+
+def apply_repetition_penalties(logits, prompt_mask, output_mask, repetition_penalties) -> None:
+    """ops.apply_repetition_penalties (vllm/_custom_ops.py:336-357): in place."""
+    _need_cuda(logits, prompt_mask, output_mask, repetition_penalties)
+    if not logits.is_contiguous():
+        raise RuntimeError("apply_repetition_penalties: logits must be contiguous")
+    pen = repetition_penalties.to(logits.dtype)
+    check(_lib.lib().mi355q_apply_repetition_penalties(
+        logits.data_ptr(), prompt_mask.contiguous().data_ptr(), output_mask.contiguous().data_ptr(),
+        pen.data_ptr(), logits.shape[0], logits.shape[1], _dt(logits, True), _stream()))
