@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Decode benchmark of the MI355X quantized-inference path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1: Llama-3-8B GPTQ int4 g128, TP=1, bf16 activations, synthetic weights and prompts
+       (BASELINE.json configs[1]).  A "step" is one decode step of the whole batch.
+N > 1: Llama-3-70B GPTQ int4 g128 with TP = N (configs[3]); launched by
+       torch.distributed.run, one rank per GPU, all-reduce over RCCL.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md for the field definitions).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vllm-fork_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--input-len", type=int, default=128)
+    ap.add_argument("--model", default=None, help="llama3-8b | llama3-70b | tiny (default: by --gpus)")
+    ap.add_argument("--quant", default="gptq", choices=["gptq", "awq", "none"])
+    ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel timing pass")
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-bf16", action="store_true")
+    ap.add_argument("--skip-ttft", action="store_true")
+    return ap.parse_args()
+
+
+def time_dominant_kernel(runner, batch, reps=6):
+    """Per-launch duration of the gate_up W4A16 GEMM (the kernel that moves most bytes of a
+    decode step), measured with an event pair around every launch on the launch stream.  The
+    launches walk over all layers' weights so no launch finds its weights in the 256 MiB
+    Infinity Cache."""
+    from mi355q import ops
+    from mi355q.model import linear_shapes, w4a16_bytes
+    K, N = linear_shapes(runner.cfg, runner.tp_size)["gate_up"]
+    x = (torch.randn((batch, K), device=runner.device) * 0.25).to(runner.dtype)
+    layers = runner.layers
+    for L in layers[:4]:
+        L["gate_up"](x)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(reps):
+        evs = []
+        for L in layers:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            L["gate_up"](x)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        times += [a.elapsed_time(b) * 1e-3 for a, b in evs]
+    avg = sum(times) / len(times)
+    nbytes = w4a16_bytes(batch, K, N, runner.G, runner.quant == "awq")
+    return {"bound": "hbm", "achieved": nbytes / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": nbytes / avg / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "w4a16_skinny_kernel (gate_up_proj %dx%d, M=%d)" % (K, N, batch),
+            "bytes_per_launch": nbytes, "avg_launch_us": avg * 1e6, "min_launch_us": min(times) * 1e6,
+            "launches": len(times)}
+
+
+def cpu_baseline(cfg, G, batch):
+    """The CPU restatement of the fork's CPU backend (oracle.cpu_gemm_wna16, the cpu_wna16.cpp
+    algorithm on its 16-channel block layout) timed on this box's host cores for a bounded sample:
+    the four projections of 4 decoder layers plus 1/8 of the lm_head, one token."""
+    import numpy as np
+    import oracle as orc
+    from mi355q.model import linear_shapes
+    cores = len(os.sched_getaffinity(0))
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    rng = np.random.default_rng(0)
+    shapes = linear_shapes(cfg, 1)
+    sample_layers = 4
+    mats = {}
+    for name, (K, N) in shapes.items():
+        qw = rng.integers(-2**31, 2**31 - 1, size=(K // 8, N), dtype=np.int32)
+        mats[name] = (orc.cpu_repack_gptq(qw), orc.f32_to_h16((0.01 * rng.random((K // G, N))).astype(np.float32)),
+                      orc.f32_to_h16(rng.standard_normal((batch, K)).astype(np.float32)))
+    vs = cfg.vocab // 8
+    lm = orc.f32_to_h16((0.02 * rng.standard_normal((vs, cfg.hidden))).astype(np.float32))
+    xh = orc.f32_to_h16(rng.standard_normal((batch, cfg.hidden)).astype(np.float32))
+    for name, (qwb, s, a) in mats.items():  # warm-up (page in, thread pool)
+        orc.cpu_gemm_wna16(a, qwb, s, None, G=G)
+    t0 = time.perf_counter()
+    for _ in range(sample_layers):
+        for name, (qwb, s, a) in mats.items():
+            orc.cpu_gemm_wna16(a, qwb, s, None, G=G)
+    t_layers = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.linear_h16(xh, lm)
+    t_lm = time.perf_counter() - t0
+    step = t_layers / sample_layers * cfg.layers + t_lm * 8
+    return {"value": batch / step, "unit": "tok/s", "cores": cores, "kind": "port",
+            "sample": "oracle cpu_gemm_wna16 (cpu_wna16.cpp restatement, 16-channel block layout) on the 4 "
+                      "projections of %d of %d layers + 1/8 of the bf16 lm_head, batch %d, extrapolated linearly "
+                      "to one full decode step; attention/norms excluded" % (sample_layers, cfg.layers, batch),
+            "sample_seconds": t_layers + t_lm}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    n_gpus = max(args.gpus, world)
+    assert world == n_gpus or world == 1 and n_gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    from mi355q.model import CONFIGS, LlamaRunner, decode_bytes_per_step
+
+    model = args.model or ("llama3-8b" if n_gpus == 1 else "llama3-70b")
+    cfg = CONFIGS[model]
+    G = 128
+    B, in_len = args.batch, args.input_len
+    max_len = in_len + args.warmup + args.steps + 8
+    max_len = (max_len + 255) // 256 * 256
+    dev = f"cuda:{local_rank if world > 1 else 0}"
+    runner = LlamaRunner(cfg, quant=args.quant, kv_cache_dtype=args.kv_dtype, group_size=G, device=dev,
+                         tp_rank=rank, tp_size=world, max_batch=B, max_seq_len=max_len)
+    torch.cuda.synchronize()
+
+    if args.roofline_only:
+        print(json.dumps({"roofline": time_dominant_kernel(runner, B)}))
+        return
+
+    # ---- TTFT: prefill of the synthetic prompt + first sampled token ------------------------
+    rng = torch.Generator().manual_seed(0)
+    prompt = torch.randint(0, min(10000, cfg.vocab), (B, in_len), generator=rng)  # vllm/benchmarks/latency.py:104
+    ttft = None
+    if not args.skip_ttft:
+        ts = []
+        for i in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            runner.prefill(prompt)
+            torch.cuda.synchronize()
+            if i >= 2:
+                ts.append(time.perf_counter() - t0)
+        ttft = statistics.median(ts) * 1e3
+    else:
+        runner.reset(in_len)
+
+    # ---- decode ------------------------------------------------------------------------------
+    graph = not args.no_graph
+    if graph:
+        try:
+            runner.capture()
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = False
+            runner.graph = None
+    for _ in range(args.warmup):
+        runner.decode_step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.decode_step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_s = elapsed / args.steps
+    tok_s = B / step_s
+    last_ids = runner.tokens.cpu().tolist()
+
+    ctx_mid = in_len + args.warmup + args.steps // 2
+    kv_bytes = 1 if args.kv_dtype == "fp8" else 2
+    if args.quant == "none":
+        from mi355q.model import linear_shapes
+        step_bytes = sum(K * N * 2 for K, N in linear_shapes(cfg, world).values()) * cfg.layers + \
+            cfg.vocab // world * cfg.hidden * 2 + 2 * cfg.layers * max(cfg.kv_heads // world, 1) * cfg.head_dim * ctx_mid * kv_bytes * B
+    else:
+        step_bytes = decode_bytes_per_step(cfg, B, ctx_mid, G, args.quant == "awq", kv_bytes, world)
+
+    out = {
+        "metric": "decode output tok/s (Llama-3-8B GPTQ-int4 TP=1 / 70B int4 TP=N), p50 TTFT in ttft_ms_p50",
+        "value": tok_s, "unit": "tok/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong" if n_gpus > 1 else "weak",
+        "vs_baseline": None, "dtype": "int4 weights x bf16 activations, fp32 accumulate", "data": "synthetic",
+        "config": {"workload": "%s %s-int4 g128 decode, TP=%d, batch %d, prompt %d, %s KV, %s" % (
+            model, args.quant, world, B, in_len, "fp8-e4m3" if args.kv_dtype == "fp8" else "bf16",
+            "hipGraph" if graph else "eager"), "parallelism": "tp%d" % world, "batch": B, "input_len": in_len},
+        "ttft_ms_p50": ttft,
+        "step_bytes_per_gpu": step_bytes,
+        "step_hbm_gbs_per_gpu": step_bytes / step_s / 1e9,
+        "step_hbm_frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+        "last_token_ids": last_ids[:4],
+    }
+    if rank == 0:
+        out["roofline"] = time_dominant_kernel(runner, B)
+    if rank == 0 and n_gpus == 1 and not args.skip_cpu:
+        out["cpu_baseline"] = cpu_baseline(cfg, G, B)
+    if rank == 0 and n_gpus == 1 and args.quant != "none" and not args.skip_bf16:
+        # the same harness on the unquantized model: the "x its own bf16 decode" comparator
+        del runner
+        torch.cuda.empty_cache()
+        r16 = LlamaRunner(cfg, quant="none", kv_cache_dtype=args.kv_dtype, device=dev, max_batch=B, max_seq_len=max_len)
+        r16.reset(in_len)
+        if graph:
+            r16.capture()
+        for _ in range(4):
+            r16.decode_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n16 = max(8, args.steps // 4)
+        for _ in range(n16):
+            r16.decode_step()
+        torch.cuda.synchronize()
+        s16 = (time.perf_counter() - t0) / n16
+        out["bf16_tok_s"] = B / s16
+        out["speedup_vs_bf16"] = s16 / step_s
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+"""Llama-shaped forward pass assembled from the CPU oracle's functions (test infrastructure).
+
+Consumes the checkpoint-layout tensors a LlamaRunner kept (keep_checkpoint=True) and generates
+greedy tokens one position at a time, so the HIP runner's prefill + decode can be compared
+token for token."""
+import numpy as np
+import torch
+
+import oracle as orc
+
+
+def _bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def _gemm(lin, x):
+    kind, qweight, scales, qzeros, G = lin.checkpoint
+    if kind == "gptq":
+        return orc.w4a16_gemm(x, qweight.numpy(), _bits(scales), None, None, G=G)
+    return orc.w4a16_gemm(x, qweight.numpy(), _bits(scales), qzeros.numpy(), None, G=G, layout=orc.W_AWQ,
+                          zp_mode=orc.ZP_AWQ)
+
+
+def oracle_generate(runner, prompt, n_new):
+    """Returns [[tok per sequence] for each of n_new generated positions]."""
+    cfg = runner.cfg
+    B, T = prompt.shape
+    D, H, KVH = cfg.head_dim, runner.heads, runner.kv_heads
+    fp8 = runner.fp8
+    x = 16 if fp8 else 8
+    bs = runner.block_size
+    nblk = runner.blocks_per_seq * runner.max_batch
+    cdt = np.uint8 if fp8 else np.uint16
+    kc = [np.zeros((nblk, KVH, D // x, bs, x), dtype=cdt) for _ in runner.layers]
+    vc = [np.zeros((nblk, KVH, D, bs), dtype=cdt) for _ in runner.layers]
+    ks, vs = float(runner.k_scale.item()), float(runner.v_scale.item())
+    bt = runner.block_tables.cpu().numpy()
+    embed, lm_head = _bits(runner.embed), _bits(runner.lm_head)
+    cache = _bits(runner.cos_sin)
+    eps = cfg.rms_eps
+
+    def step(b, tok, pos):
+        h = embed[tok][None, :].copy()
+        residual = None
+        slot = np.array([bt[b, pos // bs] * bs + pos % bs], dtype=np.int64)
+        for li, L in enumerate(runner.layers):
+            if residual is None:
+                residual = h.copy()
+                xn = orc.rms_norm(h, _bits(L["ln1"]), eps)
+            else:
+                xn, residual = orc.fused_add_rms_norm(h, residual, _bits(L["ln1"]), eps)
+            qkv = _gemm(L["qkv"], xn)
+            q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KVH) * D], qkv[:, (H + KVH) * D:]
+            q, k = orc.rotary_embedding(np.array([pos]), q, k, cache, D, True)
+            orc.reshape_and_cache(k.reshape(1, KVH, D), np.ascontiguousarray(v).reshape(1, KVH, D), kc[li], vc[li],
+                                  slot, fp8=fp8, k_scale=ks, v_scale=vs)
+            attn = orc.paged_attention(q.reshape(1, H, D), kc[li], vc[li], bt[b:b + 1], np.array([pos + 1]),
+                                       runner.scale, fp8=fp8, k_scale=ks, v_scale=vs)
+            o = _gemm(L["o"], attn.reshape(1, H * D))
+            o, residual = orc.fused_add_rms_norm(o, residual, _bits(L["ln2"]), eps)
+            gu = _gemm(L["gate_up"], o)
+            h = _gemm(L["down"], orc.silu_and_mul(gu))
+        hn, _ = orc.fused_add_rms_norm(h, residual, _bits(runner.norm), eps)
+        logits = orc.linear_h16(hn, lm_head)
+        return int(orc.argmax_h16(logits)[0])
+
+    out = [[0] * B for _ in range(n_new)]
+    for b in range(B):
+        nxt = None
+        for pos in range(T):
+            nxt = step(b, int(prompt[b, pos]), pos)
+        out[0][b] = nxt
+        for i in range(1, n_new):
+            nxt = step(b, nxt, T + i - 1)
+            out[i][b] = nxt
+    return out

@@ -71,6 +71,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `make -C vllm-fork_amd/csrc` "
                 "(there is no CPU fallback for the MI355X kernels)")
+        # torch ships its own HIP runtime under the same SONAME; it must be the one already
+        # loaded when this library resolves libamdhip64, so that kernels, streams and
+        # allocations all belong to one runtime instance
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)

@@ -1,0 +1,313 @@
+"""Llama-architecture decode/prefill runner built only from mi355q ops.
+
+This is the harness the benchmark and the end-to-end tests drive: the layer order of
+vllm/model_executor/models/llama.py:311-328 (RMSNorm -> qkv_proj -> RoPE -> KV-cache
+write -> attention -> o_proj -> fused add+RMSNorm -> gate_up_proj -> SiluAndMul ->
+down_proj), GPTQ/AWQ 4-bit linears, a 16-bit lm_head and greedy sampling, with the
+column/row tensor-parallel split of vllm/model_executor/layers/linear.py (all-reduce
+after o_proj and down_proj, linear.py:1763-1767).  Weights are synthetic.
+"""
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib, ops
+
+
+@dataclass
+class LlamaConfig:
+    name: str
+    hidden: int
+    inter: int
+    layers: int
+    heads: int
+    kv_heads: int
+    head_dim: int
+    vocab: int
+    rope_theta: float = 500000.0
+    rms_eps: float = 1e-5
+    max_pos: int = 8192
+
+
+CONFIGS = {
+    "llama3-8b": LlamaConfig("llama3-8b", 4096, 14336, 32, 32, 8, 128, 128256),
+    "llama3-70b": LlamaConfig("llama3-70b", 8192, 28672, 80, 64, 8, 128, 128256),
+    "tiny": LlamaConfig("tiny", 256, 512, 2, 4, 2, 64, 1024, max_pos=512),
+}
+
+
+def linear_shapes(cfg: LlamaConfig, tp: int = 1):
+    """Per-rank [K, N] of the four quantized projections (benchmarks/kernels/weight_shapes.py:28-33,58-63)."""
+    h, kvh = cfg.heads // tp, max(cfg.kv_heads // tp, 1)
+    return {
+        "qkv": (cfg.hidden, (h + 2 * kvh) * cfg.head_dim),
+        "o": (h * cfg.head_dim, cfg.hidden),
+        "gate_up": (cfg.hidden, 2 * cfg.inter // tp),
+        "down": (cfg.inter // tp, cfg.hidden),
+    }
+
+
+def w4a16_bytes(M: int, K: int, N: int, G: int, zeros: bool) -> int:
+    """Algorithmic bytes of one W4A16 GEMM: int4 weights + 16-bit scales (+ int4 zeros) + activations in and out."""
+    return K * N // 2 + (K // G) * N * 2 + ((K // G) * N // 2 if zeros else 0) + M * K * 2 + M * N * 2
+
+
+def decode_bytes_per_step(cfg: LlamaConfig, batch: int, ctx: int, G: int, zeros: bool, kv_bytes: int, tp: int = 1) -> int:
+    """Algorithmic HBM bytes of one decode step on one rank: quantized linears, 16-bit lm_head,
+    and the KV cache read at context `ctx` (norm/activation traffic is < 1 MB and left out)."""
+    total = 0
+    for K, N in linear_shapes(cfg, tp).values():
+        total += K * N // 2 + (K // G) * N * 2 + ((K // G) * N // 2 if zeros else 0)
+    total *= cfg.layers
+    total += cfg.vocab // tp * cfg.hidden * 2
+    kvh = max(cfg.kv_heads // tp, 1)
+    total += 2 * cfg.layers * kvh * cfg.head_dim * ctx * kv_bytes * batch
+    return total
+
+
+class Linear4:
+    """One quantized projection: checkpoint-layout tensors -> kernel layout -> apply."""
+
+    def __init__(self, K, N, G, dtype, device, gen, asym: bool, gain: float = 1.0, keep_checkpoint: bool = False):
+        self.checkpoint = None
+        qweight = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=device, generator=gen)
+        # (q - 8) has variance 21.25: keep the projection roughly norm-preserving
+        s = gain / (21.25 * K) ** 0.5
+        scales = (s * (0.5 + torch.rand((K // G, N), device=device, generator=gen))).to(dtype)
+        if asym:  # AWQ checkpoint tensors: N-packed AWQ order + packed zero points
+            qweight = qweight.view(-1)[: K * N // 8].view(K, N // 8)
+            qzeros = torch.randint(-2**31, 2**31 - 1, (K // G, N // 8), dtype=torch.int32, device=device, generator=gen)
+            self.w = ops.w4a16_repack(qweight, scales, qzeros, G, _lib.W_AWQ, _lib.ZP_AWQ)
+            if keep_checkpoint:
+                self.checkpoint = ("awq", qweight.cpu(), scales.cpu(), qzeros.cpu(), G)
+        else:
+            self.w = ops.w4a16_repack(qweight, scales, None, G, _lib.W_GPTQ, _lib.ZP_CONST)
+            if keep_checkpoint:
+                self.checkpoint = ("gptq", qweight.cpu(), scales.cpu(), None, G)
+
+    def __call__(self, x, fuse_silu_mul=False):
+        return ops.w4a16_gemm(x, self.w, fuse_silu_mul=fuse_silu_mul)
+
+
+class Linear16:
+    """Unquantized projection (the bf16 comparator model)."""
+
+    def __init__(self, K, N, dtype, device, gen, gain: float = 1.0):
+        self.weight = (torch.randn((N, K), device=device, generator=gen) * (gain / K ** 0.5)).to(dtype)
+
+    def __call__(self, x, fuse_silu_mul=False):
+        if fuse_silu_mul:
+            d = x.shape[-1] // 2
+            act = torch.empty(x.shape[:-1] + (d,), dtype=x.dtype, device=x.device)
+            ops.silu_and_mul(act, x)
+            x = act
+        if x.numel() // x.shape[-1] <= 16:
+            return ops.linear_skinny(x, self.weight)
+        return torch.nn.functional.linear(x, self.weight)
+
+
+class LlamaRunner:
+    def __init__(self, cfg: LlamaConfig, quant: str = "gptq", kv_cache_dtype: str = "auto", group_size: int = 128,
+                 dtype=torch.bfloat16, device="cuda:0", tp_rank: int = 0, tp_size: int = 1, tp_group=None,
+                 max_batch: int = 1, max_seq_len: int = 512, block_size: int = 16, seed: int = 0,
+                 keep_checkpoint: bool = False):
+        assert quant in ("gptq", "awq", "none")
+        self.cfg, self.quant, self.dtype, self.device = cfg, quant, dtype, torch.device(device)
+        self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
+        self.G = group_size
+        self.kv_cache_dtype = kv_cache_dtype
+        self.fp8 = kv_cache_dtype.startswith("fp8")
+        self.block_size, self.max_batch = block_size, max_batch
+        self.max_seq_len = max_seq_len
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(seed + 1000 * tp_rank)
+        shapes = linear_shapes(cfg, tp_size)
+        self.heads = cfg.heads // tp_size
+        self.kv_heads = max(cfg.kv_heads // tp_size, 1)
+        D = cfg.head_dim
+
+        def make(K, N, gain=1.0):
+            if quant == "none":
+                return Linear16(K, N, dtype, self.device, gen, gain)
+            return Linear4(K, N, self.G, dtype, self.device, gen, quant == "awq", gain, keep_checkpoint)
+
+        self.layers = []
+        for _ in range(cfg.layers):
+            self.layers.append({
+                "ln1": torch.ones(cfg.hidden, dtype=dtype, device=self.device),
+                "ln2": torch.ones(cfg.hidden, dtype=dtype, device=self.device),
+                "qkv": make(*shapes["qkv"]),
+                "o": make(*shapes["o"], gain=0.5),
+                "gate_up": make(*shapes["gate_up"]),
+                "down": make(*shapes["down"], gain=0.5),
+            })
+        self.norm = torch.ones(cfg.hidden, dtype=dtype, device=self.device)
+        vshard = cfg.vocab // tp_size
+        # embedding replicated, lm_head vocab-parallel
+        g2 = torch.Generator(device=self.device)
+        g2.manual_seed(seed + 7)
+        self.embed = (torch.randn((cfg.vocab, cfg.hidden), device=self.device, generator=g2) * 0.02).to(dtype)
+        self.lm_head = (torch.randn((vshard, cfg.hidden), device=self.device, generator=gen) * 0.02).to(dtype)
+
+        # RoPE cache (rotary_embedding/base.py:80-103), cast to the activation dtype (:105-131)
+        inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+        t = torch.arange(cfg.max_pos, dtype=torch.float)
+        freqs = torch.einsum("i,j -> ij", t, inv_freq)
+        self.cos_sin = torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype).to(self.device)
+
+        # paged KV cache, ROCM_ATTN layout (v1/attention/backends/rocm_attn.py:246-256, ops/paged_attn.py:16-29)
+        self.blocks_per_seq = (max_seq_len + block_size - 1) // block_size
+        nblk = self.blocks_per_seq * max_batch
+        cdt = torch.uint8 if self.fp8 else dtype
+        x = 16 // (1 if self.fp8 else 2)
+        self.kc = [torch.zeros((nblk, self.kv_heads, D // x, block_size, x), dtype=cdt, device=self.device)
+                   for _ in range(cfg.layers)]
+        self.vc = [torch.zeros((nblk, self.kv_heads, D, block_size), dtype=cdt, device=self.device)
+                   for _ in range(cfg.layers)]
+        self.k_scale = torch.full((), 1.0 / 16 if self.fp8 else 1.0, dtype=torch.float32, device=self.device)
+        self.v_scale = torch.full((), 1.0 / 16 if self.fp8 else 1.0, dtype=torch.float32, device=self.device)
+        self.block_tables = torch.arange(nblk, dtype=torch.int32, device=self.device).view(max_batch, self.blocks_per_seq)
+        self.scale = 1.0 / D ** 0.5
+        self.P = (max_seq_len + _lib.PA_PARTITION - 1) // _lib.PA_PARTITION
+
+        # static decode state (graph inputs)
+        B = max_batch
+        self.tokens = torch.zeros(B, dtype=torch.int64, device=self.device)
+        self.positions = torch.zeros(B, dtype=torch.int64, device=self.device)
+        self.seq_lens = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self.slot_base = (self.block_tables[:, 0].to(torch.int64) * block_size)  # sequences own contiguous blocks
+        self.tmp_out = torch.empty((B, self.heads, self.P, D), dtype=dtype, device=self.device)
+        self.exp_sums = torch.empty((B, self.heads, self.P), dtype=torch.float32, device=self.device)
+        self.max_logits = torch.empty_like(self.exp_sums)
+        self.graph = None
+
+    # ------------------------------------------------------------------
+    def weight_bytes(self) -> int:
+        return decode_bytes_per_step(self.cfg, 0, 0, self.G, self.quant == "awq", 0, self.tp_size) if self.quant != "none" \
+            else sum(K * N * 2 for K, N in linear_shapes(self.cfg, self.tp_size).values()) * self.cfg.layers + \
+            self.cfg.vocab // self.tp_size * self.cfg.hidden * 2
+
+    def _all_reduce(self, x):
+        if self.tp_size > 1:
+            torch.distributed.all_reduce(x, group=self.tp_group)
+        return x
+
+    def _layer(self, L, li, h, residual, positions, slot_mapping, attend):
+        cfg, D = self.cfg, self.cfg.head_dim
+        if residual is None:
+            residual = h
+            x = torch.empty_like(h)
+            ops.rms_norm(x, h, L["ln1"], cfg.rms_eps)
+        else:
+            ops.fused_add_rms_norm(h, residual, L["ln1"], cfg.rms_eps)
+            x = h
+        qkv = L["qkv"](x)
+        qs, ks = self.heads * D, self.kv_heads * D
+        q, k, v = qkv[:, :qs], qkv[:, qs:qs + ks], qkv[:, qs + ks:]
+        ops.rotary_embedding(positions, q, k, D, self.cos_sin, True)
+        T = qkv.shape[0]
+        ops.reshape_and_cache(k.view(T, self.kv_heads, D), v.view(T, self.kv_heads, D), self.kc[li], self.vc[li],
+                              slot_mapping, self.kv_cache_dtype, self.k_scale, self.v_scale)
+        attn = torch.empty((T, self.heads, D), dtype=h.dtype, device=h.device)
+        attend(li, q.view(T, self.heads, D), attn)
+        o = self._all_reduce(L["o"](attn.view(T, qs)))
+        ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
+        gu = L["gate_up"](o)
+        d = self._all_reduce(L["down"](gu, fuse_silu_mul=True))
+        return d, residual
+
+    def _logits(self, h, residual):
+        ops.fused_add_rms_norm(h, residual, self.norm, self.cfg.rms_eps)
+        M = h.shape[0]
+        logits = ops.linear_skinny(h, self.lm_head) if M <= 16 else torch.nn.functional.linear(h, self.lm_head)
+        if self.tp_size > 1:
+            parts = [torch.empty_like(logits) for _ in range(self.tp_size)]
+            torch.distributed.all_gather(parts, logits, group=self.tp_group)
+            logits = torch.cat(parts, dim=-1)
+        return logits
+
+    # ------------------------------------------------------------------
+    def prefill(self, prompt: torch.Tensor) -> torch.Tensor:
+        """prompt [B, T] token ids -> first sampled token per sequence [B]; fills the KV cache."""
+        B, T = prompt.shape
+        assert B <= self.max_batch and T <= self.max_seq_len
+        assert int(prompt.min()) >= 0 and int(prompt.max()) < self.cfg.vocab, "token id out of range"
+        dev = self.device
+        tokens = prompt.reshape(-1).to(dev)
+        positions = torch.arange(T, dtype=torch.int64, device=dev).repeat(B)
+        slot_mapping = (self.slot_base[:B, None] + torch.arange(T, dtype=torch.int64, device=dev)[None, :]).reshape(-1)
+        qsl = torch.arange(0, (B + 1) * T, T, dtype=torch.int32, device=dev)
+        seq_lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+        P = (T + _lib.PA_PARTITION - 1) // _lib.PA_PARTITION
+        tmp = torch.empty((B * T, self.heads, P, self.cfg.head_dim), dtype=self.dtype, device=dev)
+        es = torch.empty((B * T, self.heads, P), dtype=torch.float32, device=dev)
+        ml = torch.empty_like(es)
+
+        def attend(li, q, out):
+            ops.paged_prefill_attention(out, es, ml, tmp, q, self.kc[li], self.vc[li], self.kv_heads, self.scale,
+                                        self.block_tables[:B], seq_lens, qsl, T, self.block_size, T, None,
+                                        self.kv_cache_dtype, self.k_scale, self.v_scale)
+
+        h = self.embed.index_select(0, tokens)
+        residual = None
+        for li, L in enumerate(self.layers):
+            h, residual = self._layer(L, li, h, residual, positions, slot_mapping, attend)
+        last = torch.arange(T - 1, B * T, T, device=dev)
+        logits = self._logits(h.index_select(0, last), residual.index_select(0, last))
+        ids = ops.argmax(logits)
+        self.tokens[:B] = ids
+        self.positions[:B] = T
+        self.seq_lens[:B] = T + 1
+        return ids
+
+    def _decode_body(self):
+        """One decode step for the whole static batch: consumes self.tokens/positions/seq_lens,
+        leaves the sampled ids in self.tokens and advances the positions."""
+        B = self.max_batch
+        slot_mapping = self.slot_base + self.positions
+
+        def attend(li, q, out):
+            ops.paged_attention_rocm(out, self.exp_sums, self.max_logits, self.tmp_out, q, self.kc[li], self.vc[li],
+                                     self.kv_heads, self.scale, self.block_tables, self.seq_lens, None,
+                                     self.block_size, self.max_seq_len, None, self.kv_cache_dtype, self.k_scale,
+                                     self.v_scale)
+
+        h = self.embed.index_select(0, self.tokens)
+        residual = None
+        for li, L in enumerate(self.layers):
+            h, residual = self._layer(L, li, h, residual, self.positions, slot_mapping, attend)
+        ids = ops.argmax(self._logits(h, residual))
+        self.tokens.copy_(ids)
+        self.positions.add_(1)
+        self.seq_lens.add_(1)
+
+    def capture(self):
+        """Capture the decode step into a HIP graph (the reference captures the whole model forward,
+        v1/worker/gpu_model_runner.py:6834; every op here is capture-safe)."""
+        # warm up on a side stream so allocator state and the split-K workspace exist before capture
+        state = (self.tokens.clone(), self.positions.clone(), self.seq_lens.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._decode_body()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.tokens.copy_(state[0]); self.positions.copy_(state[1]); self.seq_lens.copy_(state[2])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._decode_body()
+        self.tokens.copy_(state[0]); self.positions.copy_(state[1]); self.seq_lens.copy_(state[2])
+        self.graph = g
+
+    def decode_step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._decode_body()
+
+    def reset(self, ctx: int):
+        """Pretend `ctx` tokens are already cached for every sequence (cache content stays as is)."""
+        self.tokens.fill_(1)
+        self.positions.fill_(ctx)
+        self.seq_lens.fill_(ctx + 1)
