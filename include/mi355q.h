@@ -59,8 +59,15 @@ int mi355q_version(void);
 /* ------------------------------------------------------------------ */
 
 /*
+ * Strip width (64, 32 or 16 output channels) of the tiled layout for a [K, N]
+ * layer: the narrowest strips that still give each of the 256 CUs about one
+ * strip.  The same value must be passed to the repack and to every GEMM.
+ */
+int mi355q_w4a16_choose_tile(int K, int N, int G);
+
+/*
  * Load-time repack of a 4-bit checkpoint tensor into the kernel's tiled layout
- * (1 KiB tiles of 64 output channels x 32 input channels).
+ * (1 KiB tiles of `tile` output channels x 2048/tile input channels).
  * Replaces MPLinearKernel.process_weights_after_loading
  * (mixed_precision/MPLinearKernel.py:56-58; triton_w4a16.py:338-426;
  * exllama.py:60-136 + gptq_shuffle q_gemm.cu:1857-1868).
@@ -72,17 +79,27 @@ int mi355q_version(void);
  * Requires K % 32 == 0, N % 64 == 0, G % 32 == 0 and K % G == 0 (G <= 0 means K).
  */
 int mi355q_w4a16_repack(const int32_t* qweight, const int32_t* qzeros, void* packed, void* zc,
-                        int K, int N, int G, int src_layout, int zp_mode, int act_dtype,
+                        int K, int N, int G, int tile, int src_layout, int zp_mode, int act_dtype,
                         mi355q_stream_t stream);
 /* Same arithmetic on host memory (used by load paths that repack before upload
  * and by the CPU-only tests). */
 int mi355q_w4a16_repack_host(const int32_t* qweight, const int32_t* qzeros, void* packed, void* zc,
-                             int K, int N, int G, int src_layout, int zp_mode, int act_dtype);
+                             int K, int N, int G, int tile, int src_layout, int zp_mode,
+                             int act_dtype);
 /* Inverse of the weight repack: packed tiles -> int32 [K, N] values in [0,16). */
-int mi355q_w4a16_unpack_host(const void* packed, int32_t* q, int K, int N);
+int mi355q_w4a16_unpack_host(const void* packed, int32_t* q, int K, int N, int tile);
 
 size_t mi355q_w4a16_packed_bytes(int K, int N);
+/*
+ * Split-K workspace: a block of arrival counters followed by fp32 partial tiles.
+ * The counters must be zero before the first GEMM that uses the workspace
+ * (mi355q_workspace_init, once, outside any graph capture); every GEMM leaves
+ * them zero again.  GEMMs that share one workspace must be ordered on one
+ * stream.  The reference allocates its scratch inside the op instead
+ * (q_gemm.cu:1835-1838).
+ */
 size_t mi355q_w4a16_workspace_bytes(int M, int N, int K, int G);
+int mi355q_workspace_init(void* workspace, size_t workspace_bytes, mi355q_stream_t stream);
 
 /*
  * C[M,N] = A[M,K] * ((q - z) * s)  (+ bias), fp32 accumulation, one rounding.
@@ -95,13 +112,15 @@ size_t mi355q_w4a16_workspace_bytes(int M, int N, int K, int G);
  *   zc     : from the repack, or NULL for symmetric uint4b8
  *   bias   : [N] act_dtype or NULL
  *   c      : [M, N] act_dtype, contiguous
- *   workspace : >= mi355q_w4a16_workspace_bytes(M,N,K,G) bytes (split-K partials)
+ *   tile      : strip width the weight was repacked with
+ *   workspace : >= mi355q_w4a16_workspace_bytes(M,N,K,G) bytes (only touched when K is split
+ *               across workgroups)
  *   split_k   : 0 = choose automatically
  */
 int mi355q_w4a16_gemm(const void* a, int lda, const void* packed, const void* scales,
                       const void* zc, const void* bias, void* c, int M, int N, int K, int G,
-                      int act_dtype, void* workspace, size_t workspace_bytes, int split_k,
-                      mi355q_stream_t stream);
+                      int tile, int act_dtype, void* workspace, size_t workspace_bytes,
+                      int split_k, mi355q_stream_t stream);
 
 /*
  * Same GEMM with A formed on the fly as silu(x[:, :K]) * x[:, K:] from
@@ -111,13 +130,29 @@ int mi355q_w4a16_gemm(const void* a, int lda, const void* packed, const void* sc
  */
 int mi355q_w4a16_gemm_silu_mul(const void* x, int ldx, const void* packed, const void* scales,
                                const void* zc, const void* bias, void* c, int M, int N, int K,
-                               int G, int act_dtype, void* workspace, size_t workspace_bytes,
-                               int split_k, mi355q_stream_t stream);
+                               int G, int tile, int act_dtype, void* workspace,
+                               size_t workspace_bytes, int split_k, mi355q_stream_t stream);
+
+/*
+ * Same GEMM with the preceding fused_add_rms_norm folded into its prologue:
+ *   z = round(x + residual_in)            (residual_in may be NULL: z = x)
+ *   residual_out = z                      (must not alias x or residual_in)
+ *   A = round(z * rsqrt(mean(z^2) + eps) * norm_weight)
+ *   C = A * dequant(W) (+ bias)
+ * Requires K = hidden size of the norm.  Replaces torch.ops._C.fused_add_rms_norm
+ * (layernorm_kernels.cu:106-217) / rms_norm followed by the GEMM above.
+ */
+int mi355q_w4a16_gemm_add_rms_norm(const void* x, int ldx, const void* residual_in,
+                                   void* residual_out, const void* norm_weight, float epsilon,
+                                   const void* packed, const void* scales, const void* zc,
+                                   const void* bias, void* c, int M, int N, int K, int G, int tile,
+                                   int act_dtype, void* workspace, size_t workspace_bytes,
+                                   int split_k, mi355q_stream_t stream);
 
 /* W[K,N] (act_dtype) = (q - z) * s.  Replaces ops.awq_dequantize
  * (vllm/_custom_ops.py:491-505; awq/gemm_kernels.cu:414-464). */
 int mi355q_w4a16_dequantize(const void* packed, const void* scales, const void* zc, void* w,
-                            int K, int N, int G, int act_dtype, mi355q_stream_t stream);
+                            int K, int N, int G, int tile, int act_dtype, mi355q_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* Unquantized skinny linear (lm_head, bf16 decode comparator)         */
@@ -218,6 +253,25 @@ int mi355q_paged_prefill_attention(
     const int32_t* query_start_loc, int max_query_len, int block_size, int max_seq_len,
     const float* alibi_slopes, int dtype, int kv_fp8, const float* k_scale, const float* v_scale,
     mi355q_stream_t stream);
+
+/*
+ * One decode step of attention in a single launch: NeoX RoPE (rotary_dim ==
+ * head_size) on the query and on the new key, write of the new key/value into
+ * the paged cache at position seq_lens[s] - 1, and paged attention over
+ * [0, seq_lens[s]).  qkv [S, (H + 2 KVH) * D] is the fused qkv projection
+ * output (q | k | v per row, left untouched); cos_sin_cache [max_pos, D] in
+ * `dtype`.  Same arithmetic as mi355q_rotary_embedding +
+ * mi355q_reshape_and_cache + mi355q_paged_attention (no reference counterpart
+ * as one op; the reference runs ops.rotary_embedding, ops.reshape_and_cache and
+ * ops.paged_attention_rocm back to back, rocm_attn.py:367-517).
+ */
+int mi355q_decode_attention_fused(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* qkv,
+    int64_t qkv_stride, const int64_t* positions, const void* cos_sin_cache, void* key_cache,
+    void* value_cache, int64_t kv_block_stride, int64_t kv_head_stride, int num_seqs,
+    int num_heads, int num_kv_heads, int head_size, float scale, const int32_t* block_tables,
+    int max_blocks_per_seq, const int32_t* seq_lens, int block_size, int max_seq_len, int dtype,
+    int kv_fp8, const float* k_scale, const float* v_scale, mi355q_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* Sampler inner loop                                                  */

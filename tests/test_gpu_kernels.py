@@ -454,3 +454,106 @@ def test_argmax_full_vocab_ties_and_strides():
     wide = torch.zeros((5, V + 64), dtype=torch.float32, device=DEV)
     wide[:, :V] = torch.from_numpy(x).to(DEV)
     assert ops.argmax(wide[:, :V]).cpu().numpy().tolist() == orc.argmax_f32(x).tolist()
+
+
+@pytest.mark.parametrize("M,K,N,split,with_res", [(1, 4096, 1024, 0, True), (1, 4096, 6144, 4, True), (3, 1024, 256, 1, True),
+                                                  (4, 512, 128, 2, False), (9, 256, 64, 0, True)])
+def test_w4a16_fused_add_rms_norm_prologue(M, K, N, split, with_res):
+    """GEMM with fused_add_rms_norm folded in == the oracle's norm followed by its GEMM."""
+    rng = np.random.default_rng(M + K)
+    G = 128
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    x = orc.f32_to_h16(rng.standard_normal((M, K)).astype(np.float32))
+    r = orc.f32_to_h16(rng.standard_normal((M, K)).astype(np.float32))
+    wn = orc.f32_to_h16((1 + 0.1 * rng.standard_normal(K)).astype(np.float32))
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N))).astype(np.float32))
+    qw = orc.gptq_pack(q)
+    if with_res:
+        xn, res_ref = orc.fused_add_rms_norm(x, r, wn, 1e-5)
+    else:
+        xn, res_ref = orc.rms_norm(x, wn, 1e-5), x
+    ref = orc.w4a16_gemm(xn, qw, s, None, None, G=G)
+    w = ops.w4a16_repack(i32(qw), to_dev(s), None, G)
+    xd, rd = to_dev(x), to_dev(r)
+    out, res = ops.w4a16_gemm_add_rms_norm(xd, rd if with_res else None, to_dev(wn), 1e-5, w, split_k=split)
+    assert np.array_equal(to_bits(res), res_ref)
+    assert np.array_equal(to_bits(xd), x) and np.array_equal(to_bits(rd), r)  # inputs untouched
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=2e-2)
+    assert (to_bits(out) == ref).mean() > 0.9
+
+
+def test_w4a16_split_k_counters_are_left_clean():
+    """Back-to-back split-K GEMMs of different shapes share one workspace; results stay equal to
+    the single-split result because every launch leaves the arrival counters at zero."""
+    rng = np.random.default_rng(21)
+    outs = {}
+    for rep in range(3):
+        for (M, K, N) in [(2, 2048, 256), (1, 4096, 512), (5, 1024, 128)]:
+            rs = np.random.default_rng(K + N)
+            q = rs.integers(0, 16, size=(K, N), dtype=np.int32)
+            a = orc.f32_to_h16(rs.standard_normal((M, K)).astype(np.float32))
+            s = orc.f32_to_h16((0.05 * rs.random((K // 128, N))).astype(np.float32))
+            w = ops.w4a16_repack(i32(orc.gptq_pack(q)), to_dev(s), None, 128)
+            o = ops.w4a16_gemm(to_dev(a), w, split_k=4 + rep)
+            o1 = ops.w4a16_gemm(to_dev(a), w, split_k=1)
+            np.testing.assert_allclose(o.float().cpu().numpy(), o1.float().cpu().numpy(), rtol=1e-2, atol=1e-2)
+            outs.setdefault((M, K, N), []).append(o.cpu())
+    ws = ops._WS[torch.device(DEV)]
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("H,KVH,D,bs,fp8", [(32, 8, 128, 16, False), (8, 2, 128, 32, True), (4, 4, 64, 16, False)])
+def test_decode_attention_fused_equals_unfused(H, KVH, D, bs, fp8):
+    """One launch (RoPE + cache write + attention) == rotary_embedding, reshape_and_cache,
+    paged_attention_rocm back to back: outputs and cache contents bit for bit."""
+    rng = np.random.default_rng(H * D)
+    lens = [1, 16, 130, 256, 257, 600]          # seq_len including the new token
+    S = len(lens)
+    x = 16 if fp8 else 8
+    nblk = S * ((max(lens) + bs - 1) // bs)
+    maxb = nblk // S
+    tdt = torch.uint8 if fp8 else torch.bfloat16
+    scale = 1.0 / D ** 0.5
+    ks, vs = (1 / 32, 1 / 16) if fp8 else (1.0, 1.0)
+    kst = torch.tensor(ks, dtype=torch.float32, device=DEV)
+    vst = torch.tensor(vs, dtype=torch.float32, device=DEV)
+    bt = torch.from_numpy(rng.permutation(nblk).reshape(S, maxb).astype(np.int32)).to(DEV)
+    sl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    pos = (sl - 1).to(torch.int64)
+    # a cache already holding the earlier tokens
+    if fp8:
+        kc0 = torch.from_numpy(orc.f32_to_e4m3(rng.uniform(-8, 8, (nblk, KVH, D // x, bs, x)).astype(np.float32))).to(DEV)
+        vc0 = torch.from_numpy(orc.f32_to_e4m3(rng.uniform(-8, 8, (nblk, KVH, D, bs)).astype(np.float32))).to(DEV)
+    else:
+        kc0 = torch.from_numpy(rng.uniform(-1, 1, (nblk, KVH, D // x, bs, x)).astype(np.float32)).to(torch.bfloat16).to(DEV)
+        vc0 = torch.from_numpy(rng.uniform(-1, 1, (nblk, KVH, D, bs)).astype(np.float32)).to(torch.bfloat16).to(DEV)
+    qkv = torch.from_numpy(rng.uniform(-1, 1, (S, (H + 2 * KVH) * D)).astype(np.float32)).to(torch.bfloat16).to(DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+    fr = torch.einsum("i,j->ij", torch.arange(1024, dtype=torch.float), inv)
+    cache = torch.cat((fr.cos(), fr.sin()), -1).to(torch.bfloat16).to(DEV)
+    P = (max(lens) + 255) // 256
+
+    def bufs():
+        return (torch.zeros((S, H, D), dtype=torch.bfloat16, device=DEV), torch.empty((S, H, P), dtype=torch.float32, device=DEV),
+                torch.empty((S, H, P), dtype=torch.float32, device=DEV), torch.empty((S, H, P, D), dtype=torch.bfloat16, device=DEV))
+
+    # unfused
+    kc1, vc1 = kc0.clone(), vc0.clone()
+    qkv1 = qkv.clone()
+    q1, k1, v1 = qkv1[:, :H * D], qkv1[:, H * D:(H + KVH) * D], qkv1[:, (H + KVH) * D:]
+    ops.rotary_embedding(pos, q1, k1, D, cache, True)
+    slots = torch.stack([bt[s, (lens[s] - 1) // bs].to(torch.int64) * bs + (lens[s] - 1) % bs for s in range(S)])
+    ops.reshape_and_cache(k1.view(S, KVH, D), v1.view(S, KVH, D), kc1, vc1, slots, "fp8" if fp8 else "auto", kst, vst)
+    o1, es, ml, tmp = bufs()
+    ops.paged_attention_rocm(o1, es, ml, tmp, q1.view(S, H, D), kc1, vc1, KVH, scale, bt, sl, None, bs, max(lens), None,
+                             "fp8" if fp8 else "auto", kst, vst)
+    # fused
+    kc2, vc2 = kc0.clone(), vc0.clone()
+    o2, es2, ml2, tmp2 = bufs()
+    qkv_before = qkv.clone()
+    ops.decode_attention_fused(o2, es2, ml2, tmp2, qkv, pos, cache, kc2, vc2, H, KVH, D, scale, bt, sl, bs, max(lens),
+                               "fp8" if fp8 else "auto", kst, vst)
+    assert torch.equal(qkv, qkv_before)
+    assert torch.equal(kc1.view(torch.uint8), kc2.view(torch.uint8))
+    assert torch.equal(vc1.view(torch.uint8), vc2.view(torch.uint8))
+    assert torch.equal(o1, o2)

@@ -41,6 +41,11 @@ struct PAParams {
   int varlen;          // 0: decode rows only, 1: every row, several query tokens per block
   int qblocks_per_seq; // varlen: ceil(max_query_len / QB)
   int gp;              // columns per query token (power of two >= group size)
+  // fused decode step (FUSED kernels): q points into the qkv projection output, the new
+  // token's k/v sit k_off / v_off elements after the row start; NeoX RoPE over the whole head
+  const int64_t* positions;
+  const uint16_t* cos_sin;  // [max_pos, HEAD] in the activation dtype
+  int k_off, v_off;
 };
 
 template <typename DT>
@@ -53,7 +58,22 @@ __device__ inline u32x2 fp8x4_to_h16(uint32_t v) {
   return r;
 }
 
-template <typename DT, int HEAD, bool KVFP8>
+// rotate 8 (x, y) pairs held as packed 16-bit values: x' = x c - y s, y' = y c + x s,
+// fp32 arithmetic, one rounding (csrc/libtorch_stable/pos_encoding_kernels.cu:29-32 of the reference)
+template <typename DT>
+__device__ inline void rope8(u32x4& x, u32x4& y, const u32x4 c, const u32x4 s) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const float x0 = DT::to_f32((uint16_t)(x[e] & 0xffff)), x1 = DT::to_f32((uint16_t)(x[e] >> 16));
+    const float y0 = DT::to_f32((uint16_t)(y[e] & 0xffff)), y1 = DT::to_f32((uint16_t)(y[e] >> 16));
+    const float c0 = DT::to_f32((uint16_t)(c[e] & 0xffff)), c1 = DT::to_f32((uint16_t)(c[e] >> 16));
+    const float s0 = DT::to_f32((uint16_t)(s[e] & 0xffff)), s1 = DT::to_f32((uint16_t)(s[e] >> 16));
+    x[e] = pack2<DT>(x0 * c0 - y0 * s0, x1 * c1 - y1 * s1);
+    y[e] = pack2<DT>(y0 * c0 + x0 * s0, y1 * c1 + x1 * s1);
+  }
+}
+
+template <typename DT, int HEAD, bool KVFP8, bool FUSED>
 __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) {
   __shared__ float s_max[4][16];
   __shared__ float s_sum[4][16];
@@ -98,49 +118,140 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
 
   const float scale = KVFP8 ? p.scale * (*p.k_scale) : p.scale;
   const float slope = p.alibi ? p.alibi[head] : 0.f;
-
-  // ---- Q fragments (B operand): column = this lane's query column --------------------
-  constexpr int DS = HEAD / 32;
-  u32x4 qf[DS];
-  {
-    const uint16_t* qp = p.q + (size_t)qrow * p.q_stride + (size_t)head * HEAD;
-#pragma unroll
-    for (int ds = 0; ds < DS; ds++) {
-      // 16-bit cache: k index of step ds is d = 32 ds + 8 kq + j
-      // fp8 cache   : one 16-byte K load covers d = 16 (4 (ds/2) + kq) + 8 (ds&1) + j
-      const int d0 = KVFP8 ? 16 * (4 * (ds >> 1) + kq) + 8 * (ds & 1) : 32 * ds + 8 * kq;
-      qf[ds] = *reinterpret_cast<const u32x4*>(qp + d0);
-    }
-  }
-
   const int32_t* table = p.block_tables + (size_t)seq * p.max_blocks;
   const int wave_t0 = p0 + wave * 64;
 
-  // ---- S^T = K Q^T for the wave's four 16-token tiles ----------------------------------
-  f32x4 st[4];
+  // ---- Q fragments (B operand): column = this lane's query column --------------------
+  // 16-bit cache: k index of step ds is d = 32 ds + 8 kq + j
+  // fp8 cache   : one 16-byte K load covers d = 16 (4 (ds/2) + kq) + 8 (ds&1) + j
+  constexpr int DS = HEAD / 32;
+  u32x4 qf[DS];
+  const uint16_t* qp = p.q + (size_t)qrow * p.q_stride + (size_t)head * HEAD;
+#pragma unroll
+  for (int ds = 0; ds < DS; ds++) {
+    const int d0 = KVFP8 ? 16 * (4 * (ds >> 1) + kq) + 8 * (ds & 1) : 32 * ds + 8 * kq;
+    qf[ds] = *reinterpret_cast<const u32x4*>(qp + d0);
+  }
+
+  if constexpr (FUSED) {
+    // RoPE on the query fragments: the partner d + HEAD/2 of every element sits in fragment
+    // ds + DS/2 of the same lane
+    const int64_t pos = p.positions[seq];
+    const uint16_t* cs = p.cos_sin + (size_t)pos * HEAD;
+#pragma unroll
+    for (int ds = 0; ds < DS / 2; ds++) {
+      const int d0 = KVFP8 ? 16 * (4 * (ds >> 1) + kq) + 8 * (ds & 1) : 32 * ds + 8 * kq;
+      const u32x4 c = *reinterpret_cast<const u32x4*>(cs + d0);
+      const u32x4 s = *reinterpret_cast<const u32x4*>(cs + HEAD / 2 + d0);
+      rope8<DT>(qf[ds], qf[ds + DS / 2], c, s);
+    }
+    // The workgroup whose partition holds the newest position rotates the new key and writes
+    // the new key/value into the cache before anyone reads that slot.
+    const int tnew = seq_len - 1;
+    if (part == tnew / MI355Q_PA_PARTITION) {
+      const uint16_t* rowp = p.q + (size_t)qstart * p.q_stride;
+      const int blk = table[tnew / p.bs], off = tnew % p.bs;
+      constexpr int X = KVFP8 ? 16 : 8;
+      const size_t base = (size_t)blk * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+      const int t = threadIdx.x;
+      if (t < HEAD / 2) {
+        const uint16_t* kp = rowp + p.k_off + kvh * HEAD;
+        const float x = DT::to_f32(kp[t]), y = DT::to_f32(kp[t + HEAD / 2]);
+        const float c = DT::to_f32(cs[t]), s = DT::to_f32(cs[HEAD / 2 + t]);
+        const uint16_t xr = DT::from_f32(x * c - y * s), yr = DT::from_f32(y * c + x * s);
+        const int d1 = t, d2 = t + HEAD / 2;
+        const size_t i1 = base + ((size_t)(d1 / X) * p.bs + off) * X + d1 % X;
+        const size_t i2 = base + ((size_t)(d2 / X) * p.bs + off) * X + d2 % X;
+        if constexpr (KVFP8) {
+          const float ks = *p.k_scale;
+          reinterpret_cast<uint8_t*>(const_cast<void*>(p.kc))[i1] = f32_to_fp8(DT::to_f32(xr) / ks);
+          reinterpret_cast<uint8_t*>(const_cast<void*>(p.kc))[i2] = f32_to_fp8(DT::to_f32(yr) / ks);
+        } else {
+          reinterpret_cast<uint16_t*>(const_cast<void*>(p.kc))[i1] = xr;
+          reinterpret_cast<uint16_t*>(const_cast<void*>(p.kc))[i2] = yr;
+        }
+      } else if (t >= 128 && t < 128 + HEAD) {
+        const int d = t - 128;
+        const uint16_t vb = rowp[p.v_off + kvh * HEAD + d];
+        const size_t vi = base + (size_t)d * p.bs + off;
+        if constexpr (KVFP8)
+          reinterpret_cast<uint8_t*>(const_cast<void*>(p.vc))[vi] = f32_to_fp8(DT::to_f32(vb) / *p.v_scale);
+        else
+          reinterpret_cast<uint16_t*>(const_cast<void*>(p.vc))[vi] = vb;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // ---- request K and V of the wave's four 16-token tiles -----------------------------------
+  // K: A operand rows = tokens; V^T: rows = head dims, k = tokens in the permuted order of the
+  // P fragment (element j <-> token 4 kq + j of the even tile, j >= 4: of the odd tile)
+  constexpr int DTILES = HEAD / 16;
+  constexpr int KR = KVFP8 ? DS / 2 : DS;
   int phys[4];
+  u32x4 kreg[4][KR];
+  u32x2 vreg[4][DTILES];  // 16-bit cache: 4 tokens x 16 bit; fp8: 4 tokens in [0], [1] unused
 #pragma unroll
   for (int T = 0; T < 4; T++) {
-    st[T] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int t0 = wave_t0 + T * 16;
-    phys[T] = -1;
-    if (t0 < blk_ctx) {
-      phys[T] = table[t0 / p.bs];
+    phys[T] = t0 < blk_ctx ? table[t0 / p.bs] : -1;
+  }
+#pragma unroll
+  for (int T = 0; T < 4; T++) {
+    if (phys[T] >= 0) {
+      const int t0 = wave_t0 + T * 16;
       const int off = t0 % p.bs + col;  // this lane's token row of the tile
       if constexpr (!KVFP8) {
         const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.kc) +
                              (size_t)phys[T] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
 #pragma unroll
-        for (int ds = 0; ds < DS; ds++) {
-          const u32x4 kf = *reinterpret_cast<const u32x4*>(kb + ((size_t)(ds * 4 + kq) * p.bs + off) * 8);
-          st[T] = mfma16<DT>(kf, qf[ds], st[T]);
-        }
+        for (int ds = 0; ds < DS; ds++)
+          kreg[T][ds] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(ds * 4 + kq) * p.bs + off) * 8);
       } else {
         const uint8_t* kb = reinterpret_cast<const uint8_t*>(p.kc) +
                             (size_t)phys[T] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
 #pragma unroll
+        for (int sp = 0; sp < DS / 2; sp++)
+          kreg[T][sp] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(sp * 4 + kq) * p.bs + off) * 16);
+      }
+    }
+  }
+#pragma unroll
+  for (int T = 0; T < 4; T++) {
+    if (phys[T] >= 0) {
+      const int offv = (wave_t0 + T * 16) % p.bs + 4 * kq;
+      if constexpr (!KVFP8) {
+        const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.vc) +
+                             (size_t)phys[T] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+#pragma unroll
+        for (int dt = 0; dt < DTILES; dt++)
+          vreg[T][dt] = *reinterpret_cast<const u32x2*>(vb + (size_t)(dt * 16 + col) * p.bs + offv);
+      } else {
+        const uint8_t* vb = reinterpret_cast<const uint8_t*>(p.vc) +
+                            (size_t)phys[T] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+#pragma unroll
+        for (int dt = 0; dt < DTILES; dt++) {
+          vreg[T][dt][0] = *reinterpret_cast<const uint32_t*>(vb + (size_t)(dt * 16 + col) * p.bs + offv);
+          vreg[T][dt][1] = 0u;
+        }
+      }
+    }
+  }
+
+  // ---- S^T = K Q^T ---------------------------------------------------------------------------
+  f32x4 st[4];
+#pragma unroll
+  for (int T = 0; T < 4; T++) {
+    st[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (phys[T] >= 0) {
+      if constexpr (!KVFP8) {
+#pragma unroll
+        for (int ds = 0; ds < DS; ds++) st[T] = mfma16<DT>(kreg[T][ds], qf[ds], st[T]);
+      } else {
+#pragma unroll
         for (int sp = 0; sp < DS / 2; sp++) {
-          const u32x4 raw = *reinterpret_cast<const u32x4*>(kb + ((size_t)(sp * 4 + kq) * p.bs + off) * 16);
+          const u32x4 raw = kreg[T][sp];
           const u32x2 a0 = fp8x4_to_h16<DT>(raw[0]), a1 = fp8x4_to_h16<DT>(raw[1]);
           const u32x2 b0 = fp8x4_to_h16<DT>(raw[2]), b1 = fp8x4_to_h16<DT>(raw[3]);
           st[T] = mfma16<DT>(u32x4{a0[0], a0[1], a1[0], a1[1]}, qf[2 * sp], st[T]);
@@ -185,7 +296,6 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
   const float inv = 1.0f / (sum + 1e-6f);
 
   // ---- O^T += V^T P^T ---------------------------------------------------------------------
-  constexpr int DTILES = HEAD / 16;
   f32x4 o[DTILES];
 #pragma unroll
   for (int dt = 0; dt < DTILES; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -193,50 +303,30 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
 #pragma unroll
   for (int s2 = 0; s2 < 2; s2++) {
     const int Te = 2 * s2, To = 2 * s2 + 1;
-    if (phys[Te] < 0) break;  // wave-uniform: tiles are visited in token order
-    // P fragment: k element j <-> token 4 kq + j of the even tile (j < 4), of the odd tile (j >= 4)
-    u32x4 pf;
-    pf[0] = pack2<DT>(st[Te][0] * inv, st[Te][1] * inv);
-    pf[1] = pack2<DT>(st[Te][2] * inv, st[Te][3] * inv);
-    pf[2] = pack2<DT>(st[To][0] * inv, st[To][1] * inv);
-    pf[3] = pack2<DT>(st[To][2] * inv, st[To][3] * inv);
-    // tokens at or past seq_len hold unwritten cache memory: force their V to zero
-    const int te0 = wave_t0 + Te * 16 + 4 * kq, to0 = wave_t0 + To * 16 + 4 * kq;
-    const int ne = min(max(seq_len - te0, 0), 4), no = min(max(seq_len - to0, 0), 4);
-    const uint32_t me0 = ne >= 2 ? 0xffffffffu : (ne == 1 ? 0x0000ffffu : 0u);
-    const uint32_t me1 = ne >= 4 ? 0xffffffffu : (ne == 3 ? 0x0000ffffu : 0u);
-    const uint32_t mo0 = no >= 2 ? 0xffffffffu : (no == 1 ? 0x0000ffffu : 0u);
-    const uint32_t mo1 = no >= 4 ? 0xffffffffu : (no == 3 ? 0x0000ffffu : 0u);
-    const int offe = (wave_t0 + Te * 16) % p.bs + 4 * kq;
-    const int offo = (wave_t0 + To * 16) % p.bs + 4 * kq;
-    const bool odd_ok = phys[To] >= 0;
-    if constexpr (!KVFP8) {
-      const uint16_t* vbe = reinterpret_cast<const uint16_t*>(p.vc) +
-                            (size_t)phys[Te] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
-      const uint16_t* vbo = reinterpret_cast<const uint16_t*>(p.vc) +
-                            (size_t)(odd_ok ? phys[To] : phys[Te]) * p.kv_block_stride +
-                            (size_t)kvh * p.kv_head_stride;
+    if (phys[Te] >= 0) {  // wave-uniform: tiles are visited in token order
+      u32x4 pf;
+      pf[0] = pack2<DT>(st[Te][0] * inv, st[Te][1] * inv);
+      pf[1] = pack2<DT>(st[Te][2] * inv, st[Te][3] * inv);
+      pf[2] = pack2<DT>(st[To][0] * inv, st[To][1] * inv);
+      pf[3] = pack2<DT>(st[To][2] * inv, st[To][3] * inv);
+      // tokens at or past seq_len hold unwritten cache memory: force their V to zero
+      const int te0 = wave_t0 + Te * 16 + 4 * kq, to0 = wave_t0 + To * 16 + 4 * kq;
+      const int ne = min(max(seq_len - te0, 0), 4), no = min(max(seq_len - to0, 0), 4);
+      const uint32_t me0 = ne >= 2 ? 0xffffffffu : (ne == 1 ? 0x0000ffffu : 0u);
+      const uint32_t me1 = ne >= 4 ? 0xffffffffu : (ne == 3 ? 0x0000ffffu : 0u);
+      const uint32_t mo0 = no >= 2 ? 0xffffffffu : (no == 1 ? 0x0000ffffu : 0u);
+      const uint32_t mo1 = no >= 4 ? 0xffffffffu : (no == 3 ? 0x0000ffffu : 0u);
+      const bool odd_ok = phys[To] >= 0;
 #pragma unroll
       for (int dt = 0; dt < DTILES; dt++) {
-        const size_t drow = (size_t)(dt * 16 + col) * p.bs;
-        const u32x2 ve = *reinterpret_cast<const u32x2*>(vbe + drow + offe);
-        u32x2 vo = u32x2{0u, 0u};
-        if (odd_ok) vo = *reinterpret_cast<const u32x2*>(vbo + drow + offo);
-        const u32x4 vf = u32x4{ve[0] & me0, ve[1] & me1, vo[0] & mo0, vo[1] & mo1};
-        o[dt] = mfma16<DT>(vf, pf, o[dt]);
-      }
-    } else {
-      const uint8_t* vbe = reinterpret_cast<const uint8_t*>(p.vc) +
-                           (size_t)phys[Te] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
-      const uint8_t* vbo = reinterpret_cast<const uint8_t*>(p.vc) +
-                           (size_t)(odd_ok ? phys[To] : phys[Te]) * p.kv_block_stride +
-                           (size_t)kvh * p.kv_head_stride;
-#pragma unroll
-      for (int dt = 0; dt < DTILES; dt++) {
-        const size_t drow = (size_t)(dt * 16 + col) * p.bs;
-        const u32x2 ve = fp8x4_to_h16<DT>(*reinterpret_cast<const uint32_t*>(vbe + drow + offe));
-        u32x2 vo = u32x2{0u, 0u};
-        if (odd_ok) vo = fp8x4_to_h16<DT>(*reinterpret_cast<const uint32_t*>(vbo + drow + offo));
+        u32x2 ve, vo = u32x2{0u, 0u};
+        if constexpr (!KVFP8) {
+          ve = vreg[Te][dt];
+          if (odd_ok) vo = vreg[To][dt];
+        } else {
+          ve = fp8x4_to_h16<DT>(vreg[Te][dt][0]);
+          if (odd_ok) vo = fp8x4_to_h16<DT>(vreg[To][dt][0]);
+        }
         const u32x4 vf = u32x4{ve[0] & me0, ve[1] & me1, vo[0] & mo0, vo[1] & mo1};
         o[dt] = mfma16<DT>(vf, pf, o[dt]);
       }
@@ -312,11 +402,14 @@ __global__ __launch_bounds__(HEAD) void paged_attention_reduce_kernel(const PAPa
 
 template <typename DT>
 static int launch_pa(const PAParams& p, int head_size, int kv_fp8, int qblocks, int max_qlen,
-                     hipStream_t stream) {
+                     hipStream_t stream, bool fused = false) {
   dim3 grid(qblocks, p.max_parts, p.num_kv_heads), block(256);
-#define MI355Q_PA(H, F8) hipLaunchKernelGGL((paged_attention_kernel<DT, H, F8>), grid, block, 0, stream, p)
-  if (head_size == 128) { if (kv_fp8) MI355Q_PA(128, true); else MI355Q_PA(128, false); }
-  else { if (kv_fp8) MI355Q_PA(64, true); else MI355Q_PA(64, false); }
+#define MI355Q_PA(H, F8, FU) hipLaunchKernelGGL((paged_attention_kernel<DT, H, F8, FU>), grid, block, 0, stream, p)
+  if (fused) {
+    if (head_size == 128) { if (kv_fp8) MI355Q_PA(128, true, true); else MI355Q_PA(128, false, true); }
+    else MI355Q_PA(64, false, true);
+  } else if (head_size == 128) { if (kv_fp8) MI355Q_PA(128, true, false); else MI355Q_PA(128, false, false); }
+  else { if (kv_fp8) MI355Q_PA(64, true, false); else MI355Q_PA(64, false, false); }
 #undef MI355Q_PA
   if (int e = check_launch("paged_attention_kernel")) return e;
   if (p.max_parts > 1) {
@@ -373,6 +466,7 @@ extern "C" int mi355q_paged_attention(void* out, float* exp_sums, float* max_log
   p.block_tables = block_tables; p.max_blocks = max_blocks_per_seq; p.seq_lens = seq_lens;
   p.qsl = query_start_loc; p.bs = block_size; p.alibi = alibi_slopes; p.k_scale = k_scale;
   p.v_scale = v_scale; p.varlen = 0; p.qblocks_per_seq = 1;
+  p.positions = nullptr; p.cos_sin = nullptr; p.k_off = 0; p.v_off = 0;
   if (num_seqs == 0) return MI355Q_OK;
   if (int e = pa_common(p, head_size, block_size, max_seq_len, dtype, kv_fp8, "paged_attention")) return e;
   if (dtype == MI355Q_BF16) return launch_pa<BF16>(p, head_size, kv_fp8, num_seqs, 1, (hipStream_t)stream);
@@ -395,6 +489,7 @@ extern "C" int mi355q_paged_prefill_attention(
   p.block_tables = block_tables; p.max_blocks = max_blocks_per_seq; p.seq_lens = seq_lens;
   p.qsl = query_start_loc; p.bs = block_size; p.alibi = alibi_slopes; p.k_scale = k_scale;
   p.v_scale = v_scale; p.varlen = 1;
+  p.positions = nullptr; p.cos_sin = nullptr; p.k_off = 0; p.v_off = 0;
   if (num_seqs == 0) return MI355Q_OK;
   MI355Q_REQUIRE(query_start_loc != nullptr && max_query_len > 0, "paged_prefill_attention: query_start_loc and max_query_len are required");
   if (int e = pa_common(p, head_size, block_size, max_seq_len, dtype, kv_fp8, "paged_prefill_attention")) return e;
@@ -403,4 +498,30 @@ extern "C" int mi355q_paged_prefill_attention(
   const int qblocks = num_seqs * p.qblocks_per_seq;
   if (dtype == MI355Q_BF16) return launch_pa<BF16>(p, head_size, kv_fp8, qblocks, max_query_len, (hipStream_t)stream);
   return launch_pa<FP16>(p, head_size, kv_fp8, qblocks, max_query_len, (hipStream_t)stream);
+}
+
+extern "C" int mi355q_decode_attention_fused(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* qkv, int64_t qkv_stride,
+    const int64_t* positions, const void* cos_sin_cache, void* key_cache, void* value_cache,
+    int64_t kv_block_stride, int64_t kv_head_stride, int num_seqs, int num_heads, int num_kv_heads,
+    int head_size, float scale, const int32_t* block_tables, int max_blocks_per_seq,
+    const int32_t* seq_lens, int block_size, int max_seq_len, int dtype, int kv_fp8,
+    const float* k_scale, const float* v_scale, mi355q_stream_t stream) {
+  PAParams p;
+  p.out = out; p.exp_sums = exp_sums; p.max_logits = max_logits; p.tmp_out = tmp_out;
+  p.q = (const uint16_t*)qkv; p.q_stride = qkv_stride; p.kc = key_cache; p.vc = value_cache;
+  p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  p.num_seqs = num_seqs; p.num_heads = num_heads; p.num_kv_heads = num_kv_heads; p.scale = scale;
+  p.block_tables = block_tables; p.max_blocks = max_blocks_per_seq; p.seq_lens = seq_lens;
+  p.qsl = nullptr; p.bs = block_size; p.alibi = nullptr; p.k_scale = k_scale;
+  p.v_scale = v_scale; p.varlen = 0; p.qblocks_per_seq = 1;
+  p.positions = positions; p.cos_sin = (const uint16_t*)cos_sin_cache;
+  p.k_off = num_heads * head_size; p.v_off = (num_heads + num_kv_heads) * head_size;
+  if (num_seqs == 0) return MI355Q_OK;
+  if (int e = pa_common(p, head_size, block_size, max_seq_len, dtype, kv_fp8, "decode_attention_fused")) return e;
+  MI355Q_REQUIRE(positions && cos_sin_cache, "decode_attention_fused: null pointer");
+  MI355Q_REQUIRE(head_size == 128 || !kv_fp8, "decode_attention_fused: head_size 64 with an fp8 cache is not supported");
+  MI355Q_REQUIRE(((uintptr_t)cos_sin_cache & 15) == 0, "decode_attention_fused: cos_sin_cache must be 16-byte aligned");
+  if (dtype == MI355Q_BF16) return launch_pa<BF16>(p, head_size, kv_fp8, num_seqs, 1, (hipStream_t)stream, true);
+  return launch_pa<FP16>(p, head_size, kv_fp8, num_seqs, 1, (hipStream_t)stream, true);
 }

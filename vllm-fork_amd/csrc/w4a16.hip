@@ -1,11 +1,14 @@
-// W4A16 dequant-GEMM for gfx950: tiled int4 layout, skinny (M <= 16 per pass)
-// MFMA kernel with deterministic split-K, load-time repack, dequantize.
+// W4A16 dequant-GEMM for gfx950: tiled int4 layouts, skinny (M <= 16 per pass) MFMA
+// kernel with in-block K split (and an optional deterministic cross-block split),
+// load-time repack, dequantize.
 //
-// Packed layout ("tile64x32"): the [K, N] int4 matrix is cut into tiles of 64 output
-// channels x 32 input channels (1 KiB); tiles of one 64-channel strip are consecutive
-// along K.  Inside a tile lane l of a wave owns bytes [16 l, 16 l + 16): four dwords,
-// dword i holding the 8 nibbles of
-//     n = 64 strip + 16 ((l & 15) >> 2) + 4 i + (l & 3),   k = 32 kstep + 8 (l >> 4) + j
+// Packed layout: the [K, N] int4 matrix is cut into strips of SW output channels
+// (SW = 64, 32 or 16, chosen per layer so that even narrow layers give every CU a strip)
+// and each strip into 1 KiB tiles of SW channels x (2048 / SW) input channels, consecutive
+// along K.  With NS = SW / 16 and KT = 4 / NS, lane l of a wave owns bytes [16 l, 16 l + 16)
+// of a tile: four dwords, dword i = ks * NS + sub holding the 8 nibbles of
+//     n = SW strip + (SW/4) ((l & 15) >> 2) + 4 sub + (l & 3)
+//     k = 32 (KT tile + ks) + 8 (l >> 4) + j,   j = 0..7
 // with nibble j = 2p at bits [4p, 4p+4) and j = 2p+1 at bits [16 + 4p, 16 + 4p + 4).
 // One 16-byte load per lane therefore gives the A fragments of four
 // v_mfma_f32_16x16x32 tiles, and ((w >> 4p) & 0x000F000F) | magic is directly the pair of
@@ -14,6 +17,12 @@
 // Arithmetic: per scale group, acc = sum_k a_k (bias + q_k) on the matrix cores (exact
 // products, fp32 accumulation), a1 = sum_k a_k from one extra MFMA with an all-ones A
 // operand, and the group contributes s * (acc - (bias + z) * a1) to the fp32 total.
+//
+// Latency shape: a kernel on this chip costs ~1.6 us to launch plus ~1 us per dependent
+// global-memory round trip, so the kernel requests weights, scales and activations of its
+// first chunks at entry, splits K over up to 16 waves of one workgroup (combined through
+// LDS) and writes the final 16-bit result itself; the cross-block split (ticket + last
+// arriver) is only used when a layer has too few strips to occupy the chip.
 #include <algorithm>
 #include <cstdlib>
 
@@ -38,37 +47,45 @@ __host__ __device__ static inline uint32_t src_nibble(const int32_t* qw, int lay
   return ((uint32_t)qw[(size_t)k * (N >> 3) + (n >> 3)] >> (4 * pos)) & 0xfu;
 }
 
+__host__ __device__ static inline int nibble_shift(int j) { return ((j & 1) << 4) + ((j >> 1) << 2); }
+
 // index of the packed dword holding (k, n) and the bit offset of its nibble
-__host__ __device__ static inline void packed_pos(int K, int k, int n, size_t* dword, int* shift) {
-  const int strip = n >> 6, nl = n & 63;
-  const int q = nl >> 4, i = (nl >> 2) & 3, r = nl & 3;  // row rho = 4 q + r of MFMA tile i
-  const int t = k >> 5, kq = (k >> 3) & 3, j = k & 7;
-  const int lane = (kq << 4) | (q << 2) | r;
-  *dword = (((size_t)strip * (K >> 5) + t) * 64 + lane) * 4 + i;
-  *shift = ((j & 1) << 4) + ((j >> 1) << 2);
+__host__ __device__ static inline void packed_pos(int K, int sw, int k, int n, size_t* dword,
+                                                  int* shift) {
+  const int ns = sw >> 4, kt = 4 / ns, qw = sw >> 2;
+  const int strip = n / sw, nl = n % sw;
+  const int q = nl / qw, sub = (nl % qw) >> 2, r = nl & 3;
+  const int kstep = k >> 5, tile = kstep / kt, ks = kstep % kt;
+  const int lane = (((k >> 3) & 3) << 4) | (q << 2) | r;
+  *dword = (((size_t)strip * (K / (32 * kt)) + tile) * 64 + lane) * 4 + ks * ns + sub;
+  *shift = nibble_shift(k & 7);
+}
+
+// (k0, n) of packed dword d: its nibbles are k0 .. k0 + 7 of channel n
+__host__ __device__ static inline void dword_pos(int K, int sw, size_t d, int* k0, int* n) {
+  const int ns = sw >> 4, kt = 4 / ns;
+  const int i = (int)(d & 3), lane = (int)((d >> 2) & 63);
+  const size_t tile_id = d >> 8;
+  const int tiles = K / (32 * kt);
+  const int tile = (int)(tile_id % tiles), strip = (int)(tile_id / tiles);
+  const int sub = i % ns, ks = i / ns;
+  const int rho = lane & 15, kq = lane >> 4;
+  *n = sw * strip + (sw >> 2) * (rho >> 2) + 4 * sub + (rho & 3);
+  *k0 = 32 * (kt * tile + ks) + 8 * kq;
 }
 
 __host__ __device__ static inline uint32_t repack_dword(const int32_t* qw, int layout, int K, int N,
-                                                        size_t d) {
-  (void)K;
-  const int i = (int)(d & 3);
-  const int lane = (int)((d >> 2) & 63);
-  const size_t tile = d >> 8;
-  const int ksteps = K >> 5;
-  const int t = (int)(tile % ksteps), strip = (int)(tile / ksteps);
-  const int rho = lane & 15, kq = lane >> 4;
-  const int n = 64 * strip + 16 * (rho >> 2) + 4 * i + (rho & 3);
-  const int k0 = 32 * t + 8 * kq;
+                                                        int sw, size_t d) {
+  int k0, n;
+  dword_pos(K, sw, d, &k0, &n);
   uint32_t w = 0;
   if (layout == MI355Q_W_GPTQ) {
     const uint32_t s = (uint32_t)qw[(size_t)(k0 >> 3) * N + n];
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-      w |= ((s >> (4 * j)) & 0xfu) << (((j & 1) << 4) + ((j >> 1) << 2));
+    for (int j = 0; j < 8; j++) w |= ((s >> (4 * j)) & 0xfu) << nibble_shift(j);
   } else {
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-      w |= src_nibble(qw, layout, N, k0 + j, n) << (((j & 1) << 4) + ((j >> 1) << 2));
+    for (int j = 0; j < 8; j++) w |= src_nibble(qw, layout, N, k0 + j, n) << nibble_shift(j);
   }
   return w;
 }
@@ -83,10 +100,10 @@ __host__ __device__ static inline uint16_t repack_zc(const int32_t* qz, int zp_m
 }
 
 __global__ void repack_weight_kernel(const int32_t* __restrict__ qw, uint32_t* __restrict__ out,
-                                     int K, int N, int layout, size_t ndwords) {
+                                     int K, int N, int layout, int sw, size_t ndwords) {
   for (size_t d = blockIdx.x * (size_t)blockDim.x + threadIdx.x; d < ndwords;
        d += (size_t)gridDim.x * blockDim.x)
-    out[d] = repack_dword(qw, layout, K, N, d);
+    out[d] = repack_dword(qw, layout, K, N, sw, d);
 }
 
 __global__ void repack_zc_kernel(const int32_t* __restrict__ qz, uint16_t* __restrict__ zc, int N,
@@ -97,12 +114,26 @@ __global__ void repack_zc_kernel(const int32_t* __restrict__ qz, uint16_t* __res
     zc[e] = repack_zc(qz, zp_mode, N, (int)(e / N), (int)(e % N), act_dtype);
 }
 
+static inline int chunk_steps(int G) { return (G % 128 == 0) ? 4 : (G % 64 == 0) ? 2 : 1; }
+
 static int check_shape(int K, int N, int& G) {
   if (G <= 0) G = K;
   MI355Q_REQUIRE(K > 0 && N > 0, "w4a16: K=%d N=%d must be positive", K, N);
   MI355Q_REQUIRE(K % 32 == 0, "w4a16: K=%d must be a multiple of 32", K);
   MI355Q_REQUIRE(N % 64 == 0, "w4a16: N=%d must be a multiple of 64", N);
   MI355Q_REQUIRE(G % 32 == 0 && K % G == 0, "w4a16: group size %d must divide K=%d and be a multiple of 32", G, K);
+  return 0;
+}
+
+// a tile must not straddle a scale group: 32 * KT input channels per tile
+static bool tile_ok(int sw, int K, int G) {
+  if (sw != 64 && sw != 32 && sw != 16) return false;
+  const int kt = 4 / (sw >> 4);
+  return chunk_steps(G) % kt == 0 && K % (32 * kt) == 0;
+}
+
+static int check_tile(int sw, int K, int G) {
+  MI355Q_REQUIRE(tile_ok(sw, K, G), "w4a16: tile width %d is not usable with K=%d, group size %d", sw, K, G);
   return 0;
 }
 
@@ -122,16 +153,28 @@ using namespace mi355q;
 
 extern "C" size_t mi355q_w4a16_packed_bytes(int K, int N) { return (size_t)K * N / 2; }
 
+// Strip width for a layer: the narrowest strips that still leave each of the 256 CUs about
+// one workgroup, so that no cross-block split of K is needed.
+extern "C" int mi355q_w4a16_choose_tile(int K, int N, int G) {
+  if (G <= 0) G = K;
+  const char* env = getenv("MI355Q_TILE");
+  if (env && tile_ok(atoi(env), K, G)) return atoi(env);
+  int sw = N >= 16384 ? 64 : (N >= 6144 ? 32 : 16);
+  while (sw < 64 && !tile_ok(sw, K, G)) sw <<= 1;
+  return sw;
+}
+
 extern "C" int mi355q_w4a16_repack(const int32_t* qweight, const int32_t* qzeros, void* packed,
-                                   void* zc, int K, int N, int G, int src_layout, int zp_mode,
-                                   int act_dtype, mi355q_stream_t stream) {
+                                   void* zc, int K, int N, int G, int tile, int src_layout,
+                                   int zp_mode, int act_dtype, mi355q_stream_t stream) {
   if (int e = check_shape(K, N, G)) return e;
+  if (int e = check_tile(tile, K, G)) return e;
   if (int e = check_enums(src_layout, zp_mode, act_dtype, qzeros, zc)) return e;
   MI355Q_REQUIRE(qweight && packed, "w4a16_repack: null pointer");
   const size_t nd = (size_t)K * N / 8;
   const int grid = (int)((nd + 255) / 256 < 8192 ? (nd + 255) / 256 : 8192);
   hipLaunchKernelGGL(repack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, qweight,
-                     (uint32_t*)packed, K, N, src_layout, nd);
+                     (uint32_t*)packed, K, N, src_layout, tile, nd);
   if (int e = check_launch("repack_weight_kernel")) return e;
   if (zp_mode != MI355Q_ZP_CONST) {
     const size_t nz = (size_t)(K / G) * N;
@@ -144,14 +187,15 @@ extern "C" int mi355q_w4a16_repack(const int32_t* qweight, const int32_t* qzeros
 }
 
 extern "C" int mi355q_w4a16_repack_host(const int32_t* qweight, const int32_t* qzeros,
-                                        void* packed, void* zc, int K, int N, int G,
+                                        void* packed, void* zc, int K, int N, int G, int tile,
                                         int src_layout, int zp_mode, int act_dtype) {
   if (int e = check_shape(K, N, G)) return e;
+  if (int e = check_tile(tile, K, G)) return e;
   if (int e = check_enums(src_layout, zp_mode, act_dtype, qzeros, zc)) return e;
   MI355Q_REQUIRE(qweight && packed, "w4a16_repack_host: null pointer");
   const size_t nd = (size_t)K * N / 8;
   uint32_t* out = (uint32_t*)packed;
-  for (size_t d = 0; d < nd; d++) out[d] = repack_dword(qweight, src_layout, K, N, d);
+  for (size_t d = 0; d < nd; d++) out[d] = repack_dword(qweight, src_layout, K, N, tile, d);
   if (zp_mode != MI355Q_ZP_CONST) {
     uint16_t* z = (uint16_t*)zc;
     for (int g = 0; g < K / G; g++)
@@ -160,15 +204,16 @@ extern "C" int mi355q_w4a16_repack_host(const int32_t* qweight, const int32_t* q
   return MI355Q_OK;
 }
 
-extern "C" int mi355q_w4a16_unpack_host(const void* packed, int32_t* q, int K, int N) {
+extern "C" int mi355q_w4a16_unpack_host(const void* packed, int32_t* q, int K, int N, int tile) {
   int G = K;
   if (int e = check_shape(K, N, G)) return e;
+  MI355Q_REQUIRE(tile == 64 || tile == 32 || tile == 16, "w4a16_unpack_host: bad tile width %d", tile);
   const uint32_t* p = (const uint32_t*)packed;
   for (int k = 0; k < K; k++)
     for (int n = 0; n < N; n++) {
       size_t d;
       int sh;
-      packed_pos(K, k, n, &d, &sh);
+      packed_pos(K, tile, k, n, &d, &sh);
       q[(size_t)k * N + n] = (int32_t)((p[d] >> sh) & 0xfu);
     }
   return MI355Q_OK;
@@ -179,18 +224,27 @@ extern "C" int mi355q_w4a16_unpack_host(const void* packed, int32_t* q, int K, i
 // ---------------------------------------------------------------------------
 namespace mi355q {
 
+enum { PRO_NONE = 0, PRO_SILU = 1, PRO_ADDNORM = 2 };
+
 struct SkinnyParams {
-  const uint16_t* x;       // [M, K] (or [M, 2K] gate|up when SILU)
+  const uint16_t* x;       // [M, K]; PRO_SILU: [M, 2K] gate|up; PRO_ADDNORM: the un-normed input
   int ldx;
   const u32x4* wp;         // packed tiles
   const uint16_t* scales;  // [K/G, N]
   const uint16_t* zc;      // [K/G, N] or null
   const uint16_t* bias;    // [N] or null
-  uint16_t* out;           // [M, N] (written when splits == 1)
-  float* partial;          // [splits, M, N] (written when splits > 1)
+  uint16_t* out;           // [M, N]
+  float* partial;          // [splits, M, N] split-K partial sums (splits > 1)
+  int* counters;           // [mtiles * strips] arrival tickets, zero between launches
+  // PRO_ADDNORM
+  const uint16_t* res_in;  // [M, K] or null
+  uint16_t* res_out;       // [M, K]
+  const uint16_t* norm_w;  // [K] or null
+  float eps;
   int M, N, K, G;
   int chunks;              // K / (32 * CS)
   int splits;
+  int nw;                  // waves per workgroup
 };
 
 template <typename DT>
@@ -205,31 +259,104 @@ __device__ inline u32x4 dequant_frag(uint32_t w) {
 
 __device__ inline float silu_f(float g) { return g / (1.0f + __expf(-g)); }
 
-// CS = k-steps (of 32) per flush chunk; a chunk never crosses a scale group.
-template <typename DT, int CS, bool HAS_ZC, bool SILU>
-__global__ __launch_bounds__(256) void w4a16_skinny_kernel(const SkinnyParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* red = reinterpret_cast<float*>(smem);                     // [4][16][64] fp32 = 16 KiB
-  uint16_t* act = reinterpret_cast<uint16_t*>(smem + 16384);       // SILU: [Mt][krange]
+template <int ND>
+struct Dwords {
+  uint32_t v[ND];
+};
+// ND consecutive dwords from a 4*ND-byte aligned address, as the widest loads
+template <int ND>
+__device__ inline Dwords<ND> load_dwords(const uint16_t* p) {
+  Dwords<ND> r;
+  if constexpr (ND == 8) {
+    const u32x4 a = reinterpret_cast<const u32x4*>(p)[0], b = reinterpret_cast<const u32x4*>(p)[1];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { r.v[i] = a[i]; r.v[4 + i] = b[i]; }
+  } else if constexpr (ND == 4) {
+    const u32x4 a = reinterpret_cast<const u32x4*>(p)[0];
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.v[i] = a[i];
+  } else {
+    const u32x2 a = reinterpret_cast<const u32x2*>(p)[0];
+    r.v[0] = a[0];
+    r.v[1] = a[1];
+  }
+  return r;
+}
 
+// SW = strip width, CS = k-steps (of 32) per flush chunk (a chunk never crosses a scale
+// group).  Dynamic LDS: [0, nw * NS KiB) cross-wave reduction / prologue scratch, then 16
+// bytes of flags, then the staged activations of the LDS prologues.
+// Workgroups of the 64-wide tile hold at most 8 waves (256-register budget per lane).
+template <typename DT, int SW, int CS, bool HAS_ZC, int PRO>
+__global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(const SkinnyParams p) {
+  constexpr int NS = SW / 16;      // 16-channel MFMA subtiles per k-step
+  constexpr int KT = 4 / NS;       // k-steps per 1 KiB tile
+  constexpr int CT = CS / KT;      // tiles per chunk
+  constexpr int NE = NS * 4;       // outputs per lane
+  constexpr int ND = SW / 8;       // dwords of 16-bit scales per lane and group
+  constexpr int PF = SW == 16 ? 4 : 2;  // weight chunks in flight per wave (even)
+  constexpr bool LDS_B = PRO != PRO_NONE;
+  static_assert(CS % KT == 0, "chunk must hold whole tiles");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nw = p.nw;
+  const int red_bytes = nw * NS * 1024;
+  float* red = reinterpret_cast<float*>(smem);                          // [nw][NE][64] fp32
+  int* flag = reinterpret_cast<int*>(smem + red_bytes);
+  uint16_t* act = reinterpret_cast<uint16_t*>(smem + red_bytes + 16);   // [Mt][krange]
+
+  const int nthreads = nw * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x, sp = blockIdx.y, mt = blockIdx.z;
   const int kq = lane >> 4, ml = lane & 15;
-  const int ksteps = p.K >> 5;
+  const int tiles = p.K / (32 * KT);
   const int c0 = (int)(((long long)p.chunks * sp) / p.splits);
   const int c1 = (int)(((long long)p.chunks * (sp + 1)) / p.splits);
   const int Mt = min(16, p.M - mt * 16);
   const int mrow = mt * 16 + min(ml, Mt - 1);
 
-  const u32x4* wstrip = p.wp + (size_t)strip * ksteps * 64 + lane;
+  const u32x4* wstrip = p.wp + (size_t)strip * tiles * 64 + lane;
   const uint16_t* xrow = p.x + (size_t)mrow * p.ldx + 8 * kq;
   const int kbase = c0 * CS * 32;  // first k of this block's range
+  const int krange = (c1 - c0) * CS * 32;
+  const uint16_t* arow = act + (size_t)min(ml, Mt - 1) * krange + 8 * kq;
+  const size_t sc_off = (size_t)strip * SW + (SW / 4) * kq;
 
-  if constexpr (SILU) {
+  u32x4 w[PF][CT], b[2][CS];  // activations: one chunk ahead
+  Dwords<ND> sc[PF];
+
+  auto issue_w = [&](int c, int slot) {
+#pragma unroll
+    for (int t = 0; t < CT; t++) w[slot][t] = __builtin_nontemporal_load(wstrip + (size_t)(c * CT + t) * 64);
+    const int g = (c * CS * 32) / p.G;
+    sc[slot] = load_dwords<ND>(p.scales + (size_t)g * p.N + sc_off);
+  };
+  auto issue_b = [&](int c, int slot) {
+#pragma unroll
+    for (int u = 0; u < CS; u++) {
+      const int t = c * CS + u;
+      if constexpr (LDS_B)
+        b[slot][u] = *reinterpret_cast<const u32x4*>(arow + (t * 32 - kbase));
+      else
+        b[slot][u] = *reinterpret_cast<const u32x4*>(xrow + t * 32);
+    }
+  };
+
+  // everything this wave needs first is requested before the prologue
+  const int cw = c0 + wave;
+#pragma unroll
+  for (int s = 0; s < PF; s++) {
+    const int c = cw + s * nw;
+    if (c < c1) issue_w(c, s);
+  }
+  if constexpr (!LDS_B) {
+    if (cw < c1) issue_b(cw, 0);
+  }
+
+  if constexpr (PRO == PRO_SILU) {
     // stage act[m][k - kbase] = silu(gate) * up for the block's k range, rows < Mt
-    const int krange = (c1 - c0) * CS * 32;
     const int vecs = krange >> 3;
-    for (int idx = threadIdx.x; idx < Mt * vecs; idx += 256) {
+    for (int idx = threadIdx.x; idx < Mt * vecs; idx += nthreads) {
       const int m = idx / vecs, v = idx - m * vecs;
       const uint16_t* src = p.x + (size_t)(mt * 16 + m) * p.ldx + kbase + 8 * v;
       const u32x4 g = *reinterpret_cast<const u32x4*>(src);
@@ -247,221 +374,311 @@ __global__ __launch_bounds__(256) void w4a16_skinny_kernel(const SkinnyParams p)
     }
     __syncthreads();
   }
-  const int krange_l = SILU ? (c1 - c0) * CS * 32 : 0;
-  const uint16_t* arow = act + (size_t)min(ml, Mt - 1) * krange_l + 8 * kq;
 
-  f32x4 tot[4];
+  if constexpr (PRO == PRO_ADDNORM) {
+    // z = round(x + res_in) over the whole row gives the variance; the block stages
+    // round(z * rs * w) for its own k range and strip 0 writes z to res_out for that range.
+    // Rows are handled 4 at a time.
+    const int vecs_row = p.K >> 3;
+    for (int mb = 0; mb < Mt; mb += 4) {
+      const int nm = min(4, Mt - mb);
+      float ss[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int v = threadIdx.x; v < vecs_row; v += nthreads) {
 #pragma unroll
-  for (int i = 0; i < 4; i++) tot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 4; m++) {
+          if (m < nm) {
+            const size_t off = (size_t)(mt * 16 + mb + m);
+            const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + off * p.ldx + 8 * v);
+            u32x4 rv = u32x4{0u, 0u, 0u, 0u};
+            if (p.res_in) rv = *reinterpret_cast<const u32x4*>(p.res_in + off * p.K + 8 * v);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              float a = DT::to_f32((uint16_t)(xv[e] & 0xffff)), c = DT::to_f32((uint16_t)(xv[e] >> 16));
+              if (p.res_in) {
+                a = DT::to_f32(DT::from_f32(a + DT::to_f32((uint16_t)(rv[e] & 0xffff))));
+                c = DT::to_f32(DT::from_f32(c + DT::to_f32((uint16_t)(rv[e] >> 16))));
+              }
+              ss[m] += a * a + c * c;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++) ss[m] = wave_sum(ss[m]);
+      __syncthreads();
+      if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) red[wave * 4 + m] = ss[m];
+      }
+      __syncthreads();
+      float rs[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        float t = 0.f;
+        for (int i = 0; i < nw; i++) t += red[i * 4 + m];
+        rs[m] = rsqrtf(t / (float)p.K + p.eps);
+      }
+      const int vecs = krange >> 3;
+      for (int idx = threadIdx.x; idx < nm * vecs; idx += nthreads) {
+        const int m = idx / vecs, v = idx - m * vecs;
+        const size_t off = (size_t)(mt * 16 + mb + m);
+        const int k = kbase + 8 * v;
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + off * p.ldx + k);
+        u32x4 rv = u32x4{0u, 0u, 0u, 0u}, wv = u32x4{0u, 0u, 0u, 0u};
+        if (p.res_in) rv = *reinterpret_cast<const u32x4*>(p.res_in + off * p.K + k);
+        if (p.norm_w) wv = *reinterpret_cast<const u32x4*>(p.norm_w + k);
+        const float r_m = m == 0 ? rs[0] : (m == 1 ? rs[1] : (m == 2 ? rs[2] : rs[3]));
+        u32x4 zo, o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          float a = DT::to_f32((uint16_t)(xv[e] & 0xffff)), c = DT::to_f32((uint16_t)(xv[e] >> 16));
+          if (p.res_in) {
+            a = DT::to_f32(DT::from_f32(a + DT::to_f32((uint16_t)(rv[e] & 0xffff))));
+            c = DT::to_f32(DT::from_f32(c + DT::to_f32((uint16_t)(rv[e] >> 16))));
+          }
+          zo[e] = pack2<DT>(a, c);
+          a *= r_m;
+          c *= r_m;
+          if (p.norm_w) {
+            a *= DT::to_f32((uint16_t)(wv[e] & 0xffff));
+            c *= DT::to_f32((uint16_t)(wv[e] >> 16));
+          }
+          o[e] = pack2<DT>(a, c);
+        }
+        *reinterpret_cast<u32x4*>(act + (size_t)(mb + m) * krange + 8 * v) = o;
+        if (strip == 0 && p.res_out) *reinterpret_cast<u32x4*>(p.res_out + off * p.K + k) = zo;
+      }
+      __syncthreads();
+    }
+  }
 
+  f32x4 tot[NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) tot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
-  const size_t sc_off = (size_t)strip * 64 + 16 * kq;
 
-  auto issue = [&](int c, u32x4(&w)[CS], u32x4(&b)[CS]) {
+  auto consume = [&](int c, int slot, int bslot) {
+    Dwords<ND> zz;
+    if constexpr (HAS_ZC) zz = load_dwords<ND>(p.zc + (size_t)((c * CS * 32) / p.G) * p.N + sc_off);
+    f32x4 acc[NS], acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < CS; u++) {
-      const int t = c * CS + u;
-      w[u] = __builtin_nontemporal_load(wstrip + (size_t)t * 64);
-      if constexpr (SILU)
-        b[u] = *reinterpret_cast<const u32x4*>(arow + (t * 32 - kbase));
-      else
-        b[u] = *reinterpret_cast<const u32x4*>(xrow + t * 32);
+    for (int i = 0; i < NS; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < CT; t++) {
+#pragma unroll
+      for (int ks = 0; ks < KT; ks++) {
+        const u32x4 bf = b[bslot][t * KT + ks];
+        acc1 = mfma16<DT>(ones, bf, acc1);
+#pragma unroll
+        for (int sub = 0; sub < NS; sub++)
+          acc[sub] = mfma16<DT>(dequant_frag<DT>(w[slot][t][ks * NS + sub]), bf, acc[sub]);
+      }
     }
-  };
-
-  auto consume = [&](int c, const u32x4(&w)[CS], const u32x4(&b)[CS]) {
-    const int g = (c * CS * 32) / p.G;
-    const u32x4* sp_ = reinterpret_cast<const u32x4*>(p.scales + (size_t)g * p.N + sc_off);
-    const u32x4 s_lo = sp_[0], s_hi = sp_[1];
-    u32x4 z_lo, z_hi;
-    if constexpr (HAS_ZC) {
-      const u32x4* zp_ = reinterpret_cast<const u32x4*>(p.zc + (size_t)g * p.N + sc_off);
-      z_lo = zp_[0];
-      z_hi = zp_[1];
-    }
-    f32x4 acc[4], acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    // flush: output channel e = 4 sub + r of this lane's NE (n = SW strip + (SW/4) kq + e)
 #pragma unroll
-    for (int i = 0; i < 4; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < CS; u++) {
-      acc1 = mfma16<DT>(ones, b[u], acc1);
-#pragma unroll
-      for (int i = 0; i < 4; i++) acc[i] = mfma16<DT>(dequant_frag<DT>(w[u][i]), b[u], acc[i]);
-    }
-    // flush: output channel e = 4 i + r of this lane's 16 (n = 64 strip + 16 kq + e)
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int sub = 0; sub < NS; sub++) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int e = 4 * i + r;
-        const uint32_t sw = e < 8 ? s_lo[e >> 1] : s_hi[(e - 8) >> 1];
-        const float s = DT::to_f32((uint16_t)((e & 1) ? (sw >> 16) : (sw & 0xffff)));
+        const int e = 4 * sub + r;
+        const uint32_t sw_ = sc[slot].v[e >> 1];
+        const float s = DT::to_f32((uint16_t)((e & 1) ? (sw_ >> 16) : (sw_ & 0xffff)));
         float z;
         if constexpr (HAS_ZC) {
-          const uint32_t zw = e < 8 ? z_lo[e >> 1] : z_hi[(e - 8) >> 1];
+          const uint32_t zw = zz.v[e >> 1];
           z = DT::to_f32((uint16_t)((e & 1) ? (zw >> 16) : (zw & 0xffff)));
         } else {
           z = DT::int4_bias + 8.0f;
         }
-        const float d = __builtin_fmaf(-z, acc1[r], acc[i][r]);
-        tot[i][r] = __builtin_fmaf(s, d, tot[i][r]);
+        const float d = __builtin_fmaf(-z, acc1[r], acc[sub][r]);
+        tot[sub][r] = __builtin_fmaf(s, d, tot[sub][r]);
       }
     }
   };
 
-  {
-    u32x4 w0[CS], b0[CS], w1[CS], b1[CS];
-    int c = c0 + wave;
-    if (c < c1) {
-      issue(c, w0, b0);
-      while (true) {
-        int cn = c + 4;
-        bool more = cn < c1;
-        if (more) issue(cn, w1, b1);
-        consume(c, w0, b0);
-        if (!more) break;
-        c = cn;
-        cn = c + 4;
-        more = cn < c1;
-        if (more) issue(cn, w0, b0);
-        consume(c, w1, b1);
-        if (!more) break;
-        c = cn;
+  for (int base = cw; base < c1; base += PF * nw) {
+#pragma unroll
+    for (int s = 0; s < PF; s++) {
+      const int c = base + s * nw;
+      if (c < c1) {
+        if constexpr (LDS_B) {
+          issue_b(c, s & 1);
+        } else {
+          if (c + nw < c1) issue_b(c + nw, (s + 1) & 1);
+        }
+        consume(c, s, s & 1);
+        const int cn = c + PF * nw;
+        if (cn < c1) issue_w(cn, s);
       }
     }
   }
 
-  // cross-wave reduction through LDS, then one coalesced store per thread
+  // cross-wave reduction through LDS
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int sub = 0; sub < NS; sub++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) red[(wave * 16 + 4 * i + r) * 64 + lane] = tot[i][r];
+    for (int r = 0; r < 4; r++) red[(wave * NE + 4 * sub + r) * 64 + lane] = tot[sub][r];
   __syncthreads();
 
-  const int m_l = threadIdx.x >> 4, nq = threadIdx.x & 15;
-  if (m_l < Mt) {
-    const int src_lane = 16 * (nq >> 2) + m_l, e0 = (nq & 3) * 4;
-    float v[4];
+  // thread tau < 4 SW finishes 4 consecutive channels of one activation row
+  constexpr int QW = SW / 4;
+  const int m_l = threadIdx.x / QW, nq = threadIdx.x % QW;
+  const bool active = threadIdx.x < 4 * SW && m_l < Mt;
+  const int m = mt * 16 + m_l;
+  const int n = strip * SW + 4 * nq;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const int nl = 4 * nq;
+    const int src_lane = 16 * (nl / QW) + m_l, e0 = nl % QW;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; w++) s += red[(w * 16 + e0 + j) * 64 + src_lane];
+      for (int i = 0; i < nw; i++) s += red[(i * NE + e0 + j) * 64 + src_lane];
       v[j] = s;
     }
-    const int m = mt * 16 + m_l;
-    const int n = strip * 64 + 4 * nq;
-    if (p.splits == 1) {
-      if (p.bias) {  // bias is added to the rounded GEMM result, as output.add_(bias) does
-        const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
-#pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = DT::to_f32(DT::from_f32(v[j]));
-        v[0] += DT::to_f32((uint16_t)(bb[0] & 0xffff));
-        v[1] += DT::to_f32((uint16_t)(bb[0] >> 16));
-        v[2] += DT::to_f32((uint16_t)(bb[1] & 0xffff));
-        v[3] += DT::to_f32((uint16_t)(bb[1] >> 16));
+  }
+
+  if (p.splits > 1) {
+    // Deterministic cross-block split: every block publishes its fp32 tile with write-through
+    // (agent-scope) stores, draws a ticket, and the block that draws the last ticket of the
+    // tile sums all partial tiles in split order.
+    typedef unsigned long long u64;
+    if (active) {
+      u64* dst = reinterpret_cast<u64*>(p.partial + ((size_t)sp * p.M + m) * p.N + n);
+      const u64 lo = (u64)__float_as_uint(v[0]) | ((u64)__float_as_uint(v[1]) << 32);
+      const u64 hi = (u64)__float_as_uint(v[2]) | ((u64)__float_as_uint(v[3]) << 32);
+      __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int* cnt = p.counters + (size_t)mt * gridDim.x + strip;
+      const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == p.splits - 1;
+      if (last) {
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      u32x2 o;
-      o[0] = pack2<DT>(v[0], v[1]);
-      o[1] = pack2<DT>(v[2], v[3]);
-      *reinterpret_cast<u32x2*>(p.out + (size_t)m * p.N + n) = o;
-    } else {
-      *reinterpret_cast<f32x4*>(p.partial + ((size_t)sp * p.M + m) * p.N + n) =
-          f32x4{v[0], v[1], v[2], v[3]};
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = 0.f;
+      for (int s = 0; s < p.splits; s++) {
+        const u64* src = reinterpret_cast<const u64*>(p.partial + ((size_t)s * p.M + m) * p.N + n);
+        const u64 lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[0] += __uint_as_float((uint32_t)lo);
+        v[1] += __uint_as_float((uint32_t)(lo >> 32));
+        v[2] += __uint_as_float((uint32_t)hi);
+        v[3] += __uint_as_float((uint32_t)(hi >> 32));
+      }
     }
   }
-}
 
-// out[m][n] = round(sum_s partial[s][m][n] + bias[n]); fixed summation order
-template <typename DT>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial,
-                                                            const uint16_t* __restrict__ bias,
-                                                            uint16_t* __restrict__ out, int M,
-                                                            int N, int splits) {
-  const size_t total4 = (size_t)M * N / 4;
-  for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total4;
-       v += (size_t)gridDim.x * blockDim.x) {
-    f32x4 s = reinterpret_cast<const f32x4*>(partial)[v];
-    for (int k = 1; k < splits; k++) {
-      const f32x4 t = reinterpret_cast<const f32x4*>(partial + (size_t)k * M * N)[v];
-      s += t;
-    }
-    if (bias) {
-      const int n = (int)((v * 4) % N);
-      const u32x2 bb = *reinterpret_cast<const u32x2*>(bias + n);
+  if (active) {
+    if (p.bias) {  // bias is added to the rounded GEMM result, as output.add_(bias) does
+      const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
 #pragma unroll
-      for (int j = 0; j < 4; j++) s[j] = DT::to_f32(DT::from_f32(s[j]));
-      s[0] += DT::to_f32((uint16_t)(bb[0] & 0xffff));
-      s[1] += DT::to_f32((uint16_t)(bb[0] >> 16));
-      s[2] += DT::to_f32((uint16_t)(bb[1] & 0xffff));
-      s[3] += DT::to_f32((uint16_t)(bb[1] >> 16));
+      for (int j = 0; j < 4; j++) v[j] = DT::to_f32(DT::from_f32(v[j]));
+      v[0] += DT::to_f32((uint16_t)(bb[0] & 0xffff));
+      v[1] += DT::to_f32((uint16_t)(bb[0] >> 16));
+      v[2] += DT::to_f32((uint16_t)(bb[1] & 0xffff));
+      v[3] += DT::to_f32((uint16_t)(bb[1] >> 16));
     }
     u32x2 o;
-    o[0] = pack2<DT>(s[0], s[1]);
-    o[1] = pack2<DT>(s[2], s[3]);
-    reinterpret_cast<u32x2*>(out)[v] = o;
+    o[0] = pack2<DT>(v[0], v[1]);
+    o[1] = pack2<DT>(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(p.out + (size_t)m * p.N + n) = o;
   }
 }
 
-static inline int chunk_steps(int G) { return (G % 128 == 0) ? 4 : (G % 64 == 0) ? 2 : 1; }
+// The ticket counters occupy a fixed block at the start of the workspace, so that partial
+// tiles of one GEMM shape can never land on the counters of another.
+constexpr size_t COUNTER_BYTES = 64 * 1024;
+static inline bool counters_fit(int M, int N, int sw) {
+  return (size_t)(N / sw) * ((M + 15) / 16) * sizeof(int) <= COUNTER_BYTES;
+}
 
-// Split-K heuristic: a block is 4 waves, each streaming whole chunks; about 4 blocks
-// are resident per CU (1024 slots).  Cost model in units of "one chunk per wave".
-int choose_splits(int M, int N, int K, int G, bool silu) {
+// LDS bytes one chunk of staged activations takes (LDS prologues)
+static inline size_t act_bytes_per_chunk(int CS, int M) { return (size_t)CS * 32 * std::min(M, 16) * 2; }
+constexpr size_t ACT_LDS_LIMIT = 96 * 1024;
+
+struct Plan {
+  int splits, nw;
+};
+
+// One workgroup per strip splits K over its waves; a cross-block split is added only when
+// the strips alone leave most CUs idle and K is long enough to share.
+static Plan make_plan(int M, int N, int K, int G, int sw, bool lds_prologue, int split_k) {
   const int CS = chunk_steps(G);
   const int chunks = K / (32 * CS);
-  const int strips = N / 64, mts = (M + 15) / 16;
+  const int strips = N / sw, mts = (M + 15) / 16;
+  int s = 1;
   const char* env = getenv("MI355Q_SPLITK");
-  if (env && atoi(env) > 0) return std::min(atoi(env), chunks);
-  int best = 1;
-  float best_cost = 1e30f;
-  for (int s = 1; s <= chunks && s <= 64; s++) {
-    const int per_block = (chunks + s - 1) / s;
-    if (silu && (size_t)per_block * CS * 32 * std::min(M, 16) * 2 > 64 * 1024) continue;
-    const int per_wave = (per_block + 3) / 4;
-    const long blocks = (long)strips * mts * s;
-    const int rounds = (int)((blocks + 1023) / 1024);
-    const float reduce = s == 1 ? 0.f : 0.6f + 0.08f * s * (float)std::min(M, 16) / 4.0f;
-    const float cost = (float)rounds * per_wave * (CS / 4.0f) + reduce + 0.5f;
-    if (cost < best_cost) {
-      best_cost = cost;
-      best = s;
-    }
+  if (split_k > 0) s = std::min(split_k, chunks);
+  else if (env && atoi(env) > 0) s = std::min(atoi(env), chunks);
+  else {
+    while ((long)strips * mts * s < 160 && chunks / (s * 2) >= 16) s *= 2;
   }
-  return best;
+  if (lds_prologue)
+    while (s < chunks && (size_t)((chunks + s - 1) / s) * act_bytes_per_chunk(CS, M) > ACT_LDS_LIMIT) s++;
+  if (!counters_fit(M, N, sw)) s = 1;
+  const int per_block = (chunks + s - 1) / s;
+  int nw = ((long)strips * mts * s >= 768 || sw == 64) ? 8 : 16;
+  const char* envw = getenv("MI355Q_WAVES");
+  if (envw && atoi(envw) > 0) nw = std::min(sw == 64 ? 8 : 16, atoi(envw));
+  while (nw > 4 && nw / 2 >= per_block) nw /= 2;
+  return Plan{s, nw};
 }
 
-template <typename DT, bool SILU>
-static int launch_skinny(const SkinnyParams& p, int CS, hipStream_t stream, size_t lds) {
-  dim3 grid(p.N / 64, p.splits, (p.M + 15) / 16), block(256);
-#define MI355Q_LAUNCH(cs, zc)                                                                    \
-  hipLaunchKernelGGL((w4a16_skinny_kernel<DT, cs, zc, SILU>), grid, block, lds, stream, p)
+template <typename DT, int SW, int PRO>
+static int launch_sw(const SkinnyParams& p, int CS, hipStream_t stream, size_t lds) {
+  dim3 grid(p.N / SW, p.splits, (p.M + 15) / 16), block(p.nw * 64);
   const bool zc = p.zc != nullptr;
+#define MI355Q_LAUNCH(cs, z) \
+  hipLaunchKernelGGL((w4a16_skinny_kernel<DT, SW, cs, z, PRO>), grid, block, lds, stream, p)
+  constexpr int KT = 4 / (SW / 16);
   if (CS == 4) { if (zc) MI355Q_LAUNCH(4, true); else MI355Q_LAUNCH(4, false); }
-  else if (CS == 2) { if (zc) MI355Q_LAUNCH(2, true); else MI355Q_LAUNCH(2, false); }
-  else { if (zc) MI355Q_LAUNCH(1, true); else MI355Q_LAUNCH(1, false); }
-#undef MI355Q_LAUNCH
-  if (int e = check_launch("w4a16_skinny_kernel")) return e;
-  if (p.splits > 1) {
-    const size_t total4 = (size_t)p.M * p.N / 4;
-    const int g = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL((splitk_reduce_kernel<DT>), dim3(g), dim3(256), 0, stream, p.partial, p.bias,
-                       p.out, p.M, p.N, p.splits);
-    if (int e = check_launch("splitk_reduce_kernel")) return e;
+  else if constexpr (PRO == PRO_NONE && KT <= 2) {
+    if (CS == 2) { if (zc) MI355Q_LAUNCH(2, true); else MI355Q_LAUNCH(2, false); }
+    else if constexpr (KT == 1) { if (zc) MI355Q_LAUNCH(1, true); else MI355Q_LAUNCH(1, false); }
+    else return set_error(MI355Q_EINVAL, "w4a16_gemm: group size needs a wider tile");
+  } else {
+    return set_error(MI355Q_EINVAL, "w4a16_gemm: fused prologues need a group size that is a multiple of 128");
   }
-  return MI355Q_OK;
+#undef MI355Q_LAUNCH
+  return check_launch("w4a16_skinny_kernel");
 }
+
+template <typename DT, int PRO>
+static int launch_skinny(const SkinnyParams& p, int sw, int CS, hipStream_t stream, size_t lds) {
+  if (sw == 64) return launch_sw<DT, 64, PRO>(p, CS, stream, lds);
+  if (sw == 32) return launch_sw<DT, 32, PRO>(p, CS, stream, lds);
+  return launch_sw<DT, 16, PRO>(p, CS, stream, lds);
+}
+
+struct NormArgs {
+  const void* res_in;
+  void* res_out;
+  const void* norm_w;
+  float eps;
+};
 
 static int gemm_impl(const void* x, int ldx, const void* packed, const void* scales, const void* zc,
-                     const void* bias, void* c, int M, int N, int K, int G, int act_dtype,
+                     const void* bias, void* c, int M, int N, int K, int G, int sw, int act_dtype,
                      void* workspace, size_t workspace_bytes, int split_k, hipStream_t stream,
-                     bool silu) {
+                     int pro, const NormArgs* na) {
   if (int e = check_shape(K, N, G)) return e;
+  if (int e = check_tile(sw, K, G)) return e;
   MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w4a16_gemm: act_dtype must be bf16 or fp16");
   if (M == 0) return MI355Q_OK;
   MI355Q_REQUIRE(x && packed && scales && c, "w4a16_gemm: null pointer");
   MI355Q_REQUIRE(M > 0, "w4a16_gemm: M=%d", M);
-  MI355Q_REQUIRE(ldx % 8 == 0 && ldx >= (silu ? 2 * K : K), "w4a16_gemm: row stride %d must be a multiple of 8 and cover the row", ldx);
+  MI355Q_REQUIRE(ldx % 8 == 0 && ldx >= (pro == PRO_SILU ? 2 * K : K), "w4a16_gemm: row stride %d must be a multiple of 8 and cover the row", ldx);
   MI355Q_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)scales & 15) == 0 &&
                      ((uintptr_t)c & 7) == 0 && ((uintptr_t)zc & 15) == 0 && ((uintptr_t)bias & 7) == 0,
                  "w4a16_gemm: pointers must be 16-byte aligned");
@@ -474,52 +691,67 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
   p.zc = (const uint16_t*)zc;
   p.bias = (const uint16_t*)bias;
   p.out = (uint16_t*)c;
-  p.partial = (float*)workspace;
+  p.res_in = nullptr; p.res_out = nullptr; p.norm_w = nullptr; p.eps = 0.f;
+  if (pro == PRO_ADDNORM) {
+    MI355Q_REQUIRE(na && na->res_out, "w4a16_gemm_add_rms_norm: residual_out is required");
+    MI355Q_REQUIRE(((uintptr_t)na->res_in & 15) == 0 && ((uintptr_t)na->res_out & 15) == 0 && ((uintptr_t)na->norm_w & 15) == 0,
+                   "w4a16_gemm_add_rms_norm: pointers must be 16-byte aligned");
+    MI355Q_REQUIRE(na->res_out != na->res_in && na->res_out != x, "w4a16_gemm_add_rms_norm: residual_out must not alias an input");
+    p.res_in = (const uint16_t*)na->res_in;
+    p.res_out = (uint16_t*)na->res_out;
+    p.norm_w = (const uint16_t*)na->norm_w;
+    p.eps = na->eps;
+  }
   p.M = M; p.N = N; p.K = K; p.G = G;
   p.chunks = K / (32 * CS);
-  int splits = split_k > 0 ? std::min(split_k, p.chunks) : choose_splits(M, N, K, G, silu);
-  size_t lds = 16384;
-  if (silu) {
-    const size_t row_bytes = (size_t)CS * 32 * std::min(M, 16) * 2;  // LDS bytes per chunk
-    while (splits < p.chunks && (size_t)((p.chunks + splits - 1) / splits) * row_bytes > 64 * 1024) splits++;
-    const int pb = (p.chunks + splits - 1) / splits;
-    lds += (size_t)(pb + 1) * CS * 32 * std::min(M, 16) * 2;
-    MI355Q_REQUIRE(lds <= 160 * 1024 - 1024, "w4a16_gemm_silu_mul: K range per block does not fit LDS");
+  const bool lds_pro = pro != PRO_NONE;
+  const Plan plan = make_plan(M, N, K, G, sw, lds_pro, split_k);
+  p.splits = plan.splits;
+  p.nw = plan.nw;
+  size_t lds = (size_t)p.nw * (sw / 16) * 1024 + 16;
+  if (lds_pro) {
+    const int pb = (p.chunks + p.splits - 1) / p.splits;
+    lds += (size_t)pb * act_bytes_per_chunk(CS, M);
   }
-  p.splits = splits;
-  if (splits > 1) {
-    MI355Q_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "w4a16_gemm: split-K needs a 16-byte aligned workspace");
-    if (workspace_bytes < (size_t)splits * M * N * sizeof(float))
-      return set_error(MI355Q_ENOSPACE, "w4a16_gemm: workspace %zu B < %zu B", workspace_bytes,
-                       (size_t)splits * M * N * sizeof(float));
+  MI355Q_REQUIRE(lds <= 160 * 1024, "w4a16_gemm: %zu bytes of LDS needed (K range per block too long)", lds);
+  p.counters = nullptr;
+  p.partial = nullptr;
+  if (p.splits > 1) {
+    MI355Q_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 255) == 0, "w4a16_gemm: split-K needs a 256-byte aligned workspace");
+    const size_t need = COUNTER_BYTES + (size_t)p.splits * M * N * sizeof(float);
+    if (workspace_bytes < need)
+      return set_error(MI355Q_ENOSPACE, "w4a16_gemm: workspace %zu B < %zu B", workspace_bytes, need);
+    p.counters = (int*)workspace;
+    p.partial = (float*)((char*)workspace + COUNTER_BYTES);
   }
-  if (act_dtype == MI355Q_BF16)
-    return silu ? launch_skinny<BF16, true>(p, CS, stream, lds) : launch_skinny<BF16, false>(p, CS, stream, lds);
-  return silu ? launch_skinny<FP16, true>(p, CS, stream, lds) : launch_skinny<FP16, false>(p, CS, stream, lds);
+#define MI355Q_PRO(DTT)                                                                \
+  switch (pro) {                                                                       \
+    case PRO_SILU: return launch_skinny<DTT, PRO_SILU>(p, sw, CS, stream, lds);        \
+    case PRO_ADDNORM: return launch_skinny<DTT, PRO_ADDNORM>(p, sw, CS, stream, lds);  \
+    default: return launch_skinny<DTT, PRO_NONE>(p, sw, CS, stream, lds);              \
+  }
+  if (act_dtype == MI355Q_BF16) { MI355Q_PRO(BF16) }
+  MI355Q_PRO(FP16)
+#undef MI355Q_PRO
 }
 
 // ---- dequantize ---------------------------------------------------------------
 template <typename DT>
 __global__ void dequantize_kernel(const uint32_t* __restrict__ wp, const uint16_t* __restrict__ scales,
                                   const uint16_t* __restrict__ zc, uint16_t* __restrict__ W, int K,
-                                  int N, int G) {
+                                  int N, int G, int sw) {
   const size_t nd = (size_t)K * N / 8;
-  const int ksteps = K >> 5;
   for (size_t d = blockIdx.x * (size_t)blockDim.x + threadIdx.x; d < nd;
        d += (size_t)gridDim.x * blockDim.x) {
-    const int i = (int)(d & 3), lane = (int)((d >> 2) & 63);
-    const size_t tile = d >> 8;
-    const int t = (int)(tile % ksteps), strip = (int)(tile / ksteps);
-    const int rho = lane & 15, kq = lane >> 4;
-    const int n = 64 * strip + 16 * (rho >> 2) + 4 * i + (rho & 3);
-    const int k0 = 32 * t + 8 * kq;
+    int k0, n;
+    dword_pos(K, sw, d, &k0, &n);
     const int g = k0 / G;
     const float s = DT::to_f32(scales[(size_t)g * N + n]);
     const float z = zc ? DT::to_f32(zc[(size_t)g * N + n]) - DT::int4_bias : 8.0f;
     const uint32_t w = wp[d];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const float q = (float)((w >> (((j & 1) << 4) + ((j >> 1) << 2))) & 0xfu);
+      const float q = (float)((w >> nibble_shift(j)) & 0xfu);
       W[(size_t)(k0 + j) * N + n] = DT::from_f32((q - z) * s);
     }
   }
@@ -533,30 +765,50 @@ extern "C" size_t mi355q_w4a16_workspace_bytes(int M, int N, int K, int G) {
   const int CS = chunk_steps(G);
   const int chunks = K / (32 * CS);
   const int smax = chunks < 64 ? chunks : 64;
-  return (size_t)smax * M * N * sizeof(float);
+  return COUNTER_BYTES + (size_t)smax * M * N * sizeof(float);
+}
+
+extern "C" int mi355q_workspace_init(void* workspace, size_t workspace_bytes, mi355q_stream_t stream) {
+  MI355Q_REQUIRE(workspace != nullptr, "workspace_init: null workspace");
+  hipError_t e = hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream);
+  if (e != hipSuccess) return set_error(MI355Q_EHIP, "workspace_init: %s", hipGetErrorString(e));
+  return MI355Q_OK;
 }
 
 extern "C" int mi355q_w4a16_gemm(const void* a, int lda, const void* packed, const void* scales,
                                  const void* zc, const void* bias, void* c, int M, int N, int K,
-                                 int G, int act_dtype, void* workspace, size_t workspace_bytes,
-                                 int split_k, mi355q_stream_t stream) {
-  return gemm_impl(a, lda, packed, scales, zc, bias, c, M, N, K, G, act_dtype, workspace,
-                   workspace_bytes, split_k, (hipStream_t)stream, false);
+                                 int G, int tile, int act_dtype, void* workspace,
+                                 size_t workspace_bytes, int split_k, mi355q_stream_t stream) {
+  return gemm_impl(a, lda, packed, scales, zc, bias, c, M, N, K, G, tile, act_dtype, workspace,
+                   workspace_bytes, split_k, (hipStream_t)stream, PRO_NONE, nullptr);
 }
 
 extern "C" int mi355q_w4a16_gemm_silu_mul(const void* x, int ldx, const void* packed,
                                           const void* scales, const void* zc, const void* bias,
-                                          void* c, int M, int N, int K, int G, int act_dtype,
-                                          void* workspace, size_t workspace_bytes, int split_k,
-                                          mi355q_stream_t stream) {
-  return gemm_impl(x, ldx, packed, scales, zc, bias, c, M, N, K, G, act_dtype, workspace,
-                   workspace_bytes, split_k, (hipStream_t)stream, true);
+                                          void* c, int M, int N, int K, int G, int tile,
+                                          int act_dtype, void* workspace, size_t workspace_bytes,
+                                          int split_k, mi355q_stream_t stream) {
+  return gemm_impl(x, ldx, packed, scales, zc, bias, c, M, N, K, G, tile, act_dtype, workspace,
+                   workspace_bytes, split_k, (hipStream_t)stream, PRO_SILU, nullptr);
+}
+
+extern "C" int mi355q_w4a16_gemm_add_rms_norm(const void* x, int ldx, const void* residual_in,
+                                              void* residual_out, const void* norm_weight,
+                                              float epsilon, const void* packed, const void* scales,
+                                              const void* zc, const void* bias, void* c, int M, int N,
+                                              int K, int G, int tile, int act_dtype, void* workspace,
+                                              size_t workspace_bytes, int split_k,
+                                              mi355q_stream_t stream) {
+  NormArgs na{residual_in, residual_out, norm_weight, epsilon};
+  return gemm_impl(x, ldx, packed, scales, zc, bias, c, M, N, K, G, tile, act_dtype, workspace,
+                   workspace_bytes, split_k, (hipStream_t)stream, PRO_ADDNORM, &na);
 }
 
 extern "C" int mi355q_w4a16_dequantize(const void* packed, const void* scales, const void* zc,
-                                       void* w, int K, int N, int G, int act_dtype,
+                                       void* w, int K, int N, int G, int tile, int act_dtype,
                                        mi355q_stream_t stream) {
   if (int e = check_shape(K, N, G)) return e;
+  if (int e = check_tile(tile, K, G)) return e;
   MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w4a16_dequantize: act_dtype must be bf16 or fp16");
   MI355Q_REQUIRE(packed && scales && w, "w4a16_dequantize: null pointer");
   const size_t nd = (size_t)K * N / 8;
@@ -564,10 +816,10 @@ extern "C" int mi355q_w4a16_dequantize(const void* packed, const void* scales, c
   if (act_dtype == MI355Q_BF16)
     hipLaunchKernelGGL((dequantize_kernel<BF16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const uint32_t*)packed, (const uint16_t*)scales, (const uint16_t*)zc,
-                       (uint16_t*)w, K, N, G);
+                       (uint16_t*)w, K, N, G, tile);
   else
     hipLaunchKernelGGL((dequantize_kernel<FP16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const uint32_t*)packed, (const uint16_t*)scales, (const uint16_t*)zc,
-                       (uint16_t*)w, K, N, G);
+                       (uint16_t*)w, K, N, G, tile);
   return check_launch("dequantize_kernel");
 }

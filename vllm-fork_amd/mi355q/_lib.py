@@ -26,16 +26,20 @@ c_int, c_i64, c_f32, c_sz, c_vp = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
 _SIGS = {
     "mi355q_last_error": (ctypes.c_char_p, []),
     "mi355q_version": (c_int, []),
-    "mi355q_w4a16_repack": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
-    "mi355q_w4a16_repack_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "mi355q_w4a16_unpack_host": (c_int, [c_vp, c_vp, c_int, c_int]),
+    "mi355q_w4a16_choose_tile": (c_int, [c_int, c_int, c_int]),
+    "mi355q_w4a16_repack": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_w4a16_repack_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mi355q_w4a16_unpack_host": (c_int, [c_vp, c_vp, c_int, c_int, c_int]),
     "mi355q_w4a16_packed_bytes": (c_sz, [c_int, c_int]),
     "mi355q_w4a16_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "mi355q_workspace_init": (c_int, [c_vp, c_sz, c_vp]),
+    "mi355q_w4a16_gemm_add_rms_norm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                               c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_int, c_vp]),
     "mi355q_w4a16_gemm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                  c_int, c_vp, c_sz, c_int, c_vp]),
+                                  c_int, c_int, c_vp, c_sz, c_int, c_vp]),
     "mi355q_w4a16_gemm_silu_mul": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int,
-                                           c_int, c_int, c_vp, c_sz, c_int, c_vp]),
-    "mi355q_w4a16_dequantize": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+                                           c_int, c_int, c_int, c_vp, c_sz, c_int, c_vp]),
+    "mi355q_w4a16_dequantize": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_linear_skinny": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_rms_norm": (c_int, [c_vp, c_vp, c_i64, c_vp, c_f32, c_int, c_int, c_int, c_vp]),
     "mi355q_fused_add_rms_norm": (c_int, [c_vp, c_i64, c_vp, c_vp, c_f32, c_int, c_int, c_int, c_vp]),
@@ -52,6 +56,9 @@ _SIGS = {
     "mi355q_paged_prefill_attention": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64,
                                                c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_vp,
                                                c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "mi355q_decode_attention_fused": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64,
+                                              c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_int, c_int,
+                                              c_int, c_int, c_vp, c_vp, c_vp]),
     "mi355q_argmax": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_vp]),
     "mi355q_apply_repetition_penalties": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
 }

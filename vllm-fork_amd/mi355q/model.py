@@ -194,25 +194,40 @@ class LlamaRunner:
 
     def _layer(self, L, li, h, residual, positions, slot_mapping, attend):
         cfg, D = self.cfg, self.cfg.head_dim
-        if residual is None:
-            residual = h
-            x = torch.empty_like(h)
-            ops.rms_norm(x, h, L["ln1"], cfg.rms_eps)
+        T = h.shape[0]
+        # small token counts: the add+RMSNorm runs in the prologue of the GEMM that consumes it
+        fuse_norm = self.quant != "none" and T <= 4
+        if fuse_norm:
+            qkv, residual = ops.w4a16_gemm_add_rms_norm(h, residual, L["ln1"], cfg.rms_eps, L["qkv"].w)
         else:
-            ops.fused_add_rms_norm(h, residual, L["ln1"], cfg.rms_eps)
-            x = h
-        qkv = L["qkv"](x)
+            if residual is None:
+                residual = h
+                x = torch.empty_like(h)
+                ops.rms_norm(x, h, L["ln1"], cfg.rms_eps)
+            else:
+                ops.fused_add_rms_norm(h, residual, L["ln1"], cfg.rms_eps)
+                x = h
+            qkv = L["qkv"](x)
         qs, ks = self.heads * D, self.kv_heads * D
-        q, k, v = qkv[:, :qs], qkv[:, qs:qs + ks], qkv[:, qs + ks:]
-        ops.rotary_embedding(positions, q, k, D, self.cos_sin, True)
-        T = qkv.shape[0]
-        ops.reshape_and_cache(k.view(T, self.kv_heads, D), v.view(T, self.kv_heads, D), self.kc[li], self.vc[li],
-                              slot_mapping, self.kv_cache_dtype, self.k_scale, self.v_scale)
         attn = torch.empty((T, self.heads, D), dtype=h.dtype, device=h.device)
-        attend(li, q.view(T, self.heads, D), attn)
+        if attend is None:
+            # decode: RoPE + cache write + attention in one launch
+            ops.decode_attention_fused(attn, self.exp_sums, self.max_logits, self.tmp_out, qkv, positions,
+                                       self.cos_sin, self.kc[li], self.vc[li], self.heads, self.kv_heads, D,
+                                       self.scale, self.block_tables, self.seq_lens, self.block_size,
+                                       self.max_seq_len, self.kv_cache_dtype, self.k_scale, self.v_scale)
+        else:
+            q, k, v = qkv[:, :qs], qkv[:, qs:qs + ks], qkv[:, qs + ks:]
+            ops.rotary_embedding(positions, q, k, D, self.cos_sin, True)
+            ops.reshape_and_cache(k.view(T, self.kv_heads, D), v.view(T, self.kv_heads, D), self.kc[li], self.vc[li],
+                                  slot_mapping, self.kv_cache_dtype, self.k_scale, self.v_scale)
+            attend(li, q.view(T, self.heads, D), attn)
         o = self._all_reduce(L["o"](attn.view(T, qs)))
-        ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
-        gu = L["gate_up"](o)
+        if fuse_norm:
+            gu, residual = ops.w4a16_gemm_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps, L["gate_up"].w)
+        else:
+            ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
+            gu = L["gate_up"](o)
         d = self._all_reduce(L["down"](gu, fuse_silu_mul=True))
         return d, residual
 
@@ -265,12 +280,13 @@ class LlamaRunner:
         leaves the sampled ids in self.tokens and advances the positions."""
         B = self.max_batch
         slot_mapping = self.slot_base + self.positions
-
-        def attend(li, q, out):
-            ops.paged_attention_rocm(out, self.exp_sums, self.max_logits, self.tmp_out, q, self.kc[li], self.vc[li],
-                                     self.kv_heads, self.scale, self.block_tables, self.seq_lens, None,
-                                     self.block_size, self.max_seq_len, None, self.kv_cache_dtype, self.k_scale,
-                                     self.v_scale)
+        attend = None
+        if self.fp8 and self.cfg.head_dim != 128:  # the fused step needs head 128 with an fp8 cache
+            def attend(li, q, out):
+                ops.paged_attention_rocm(out, self.exp_sums, self.max_logits, self.tmp_out, q, self.kc[li], self.vc[li],
+                                         self.kv_heads, self.scale, self.block_tables, self.seq_lens, None,
+                                         self.block_size, self.max_seq_len, None, self.kv_cache_dtype, self.k_scale,
+                                         self.v_scale)
 
         h = self.embed.index_select(0, self.tokens)
         residual = None

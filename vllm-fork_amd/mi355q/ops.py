@@ -41,14 +41,15 @@ def _need_cuda(*ts):
 class PackedW4:
     """Kernel-layout 4-bit weight of one linear layer (output of `w4a16_repack`)."""
 
-    __slots__ = ("packed", "scales", "zc", "K", "N", "G")
+    __slots__ = ("packed", "scales", "zc", "K", "N", "G", "tile")
 
-    def __init__(self, packed, scales, zc, K, N, G):
-        self.packed, self.scales, self.zc, self.K, self.N, self.G = packed, scales, zc, K, N, G
+    def __init__(self, packed, scales, zc, K, N, G, tile):
+        self.packed, self.scales, self.zc, self.K, self.N, self.G, self.tile = packed, scales, zc, K, N, G, tile
 
 
 def w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor | None,
-                 group_size: int, src_layout: int = _lib.W_GPTQ, zp_mode: int = _lib.ZP_CONST) -> PackedW4:
+                 group_size: int, src_layout: int = _lib.W_GPTQ, zp_mode: int = _lib.ZP_CONST,
+                 tile: int = 0) -> PackedW4:
     """Checkpoint tensors -> kernel layout.  Stands in for
     MPLinearKernel.process_weights_after_loading (mixed_precision/triton_w4a16.py:338-426).
     Works on device tensors (HIP kernel) and on CPU tensors (host arithmetic, for load
@@ -71,24 +72,29 @@ def w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tens
         qzeros = qzeros.contiguous()
         zc = torch.empty((K // G, N), dtype=scales.dtype, device=qweight.device)
     L = _lib.lib()
+    if tile == 0:
+        tile = L.mi355q_w4a16_choose_tile(K, N, G)
     if qweight.is_cuda:
         check(L.mi355q_w4a16_repack(qweight.data_ptr(), _ptr(qzeros if zc is not None else None),
-                                    packed.data_ptr(), _ptr(zc), K, N, G, src_layout, zp_mode, act, _stream()))
+                                    packed.data_ptr(), _ptr(zc), K, N, G, tile, src_layout, zp_mode, act, _stream()))
     else:
         check(L.mi355q_w4a16_repack_host(qweight.data_ptr(), _ptr(qzeros if zc is not None else None),
-                                         packed.data_ptr(), _ptr(zc), K, N, G, src_layout, zp_mode, act))
-    return PackedW4(packed, scales.contiguous(), zc, K, N, G)
+                                         packed.data_ptr(), _ptr(zc), K, N, G, tile, src_layout, zp_mode, act))
+    return PackedW4(packed, scales.contiguous(), zc, K, N, G, tile)
 
 
 _WS: dict = {}
 
 
 def _workspace(dev, nbytes: int) -> torch.Tensor:
-    """Per-device split-K workspace, grown on demand (outside graph capture) and then
-    reused; under capture the pointer is therefore stable."""
+    """Per-device split-K workspace (arrival counters + fp32 partial tiles).  Created zeroed,
+    grown on demand outside graph capture and then reused, so its address is stable under
+    capture; GEMMs leave the counters zero."""
     ws = _WS.get(dev)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 24), dtype=torch.uint8, device=dev)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("split-K workspace must be sized before graph capture (run the op once eagerly)")
+        ws = torch.zeros(max(nbytes, 1 << 24), dtype=torch.uint8, device=dev)
         _WS[dev] = ws
     return ws
 
@@ -115,8 +121,32 @@ def w4a16_gemm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, s
     ws = _workspace(x.device, ws_bytes)
     fn = L.mi355q_w4a16_gemm_silu_mul if fuse_silu_mul else L.mi355q_w4a16_gemm
     check(fn(x2.data_ptr(), x2.stride(0), w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc), _ptr(bias),
-             out.data_ptr(), M, w.N, w.K, w.G, _dt(x), ws.data_ptr(), ws.numel(), split_k, _stream()))
+             out.data_ptr(), M, w.N, w.K, w.G, w.tile, _dt(x), ws.data_ptr(), ws.numel(), split_k, _stream()))
     return out.reshape(x.shape[:-1] + (w.N,))
+
+
+def w4a16_gemm_add_rms_norm(x: torch.Tensor, residual: torch.Tensor | None, norm_weight: torch.Tensor | None,
+                            epsilon: float, w: PackedW4, bias: torch.Tensor | None = None, split_k: int = 0):
+    """fused_add_rms_norm(x, residual) followed by the W4A16 GEMM, in one kernel.
+    Returns (gemm output, new residual); x and residual are left untouched."""
+    _need_cuda(x, w.packed)
+    if x.shape[-1] != w.K:
+        raise RuntimeError(f"input feature size {x.shape[-1]} != {w.K}")
+    x2 = x.reshape(-1, w.K)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if residual is not None and (not residual.is_contiguous() or residual.numel() != M * w.K):
+        raise RuntimeError("residual must be a contiguous [tokens, hidden] tensor")
+    out = torch.empty((M, w.N), dtype=x.dtype, device=x.device)
+    res_out = torch.empty((M, w.K), dtype=x.dtype, device=x.device)
+    L = _lib.lib()
+    ws = _workspace(x.device, L.mi355q_w4a16_workspace_bytes(M, w.N, w.K, w.G))
+    check(L.mi355q_w4a16_gemm_add_rms_norm(
+        x2.data_ptr(), x2.stride(0), _ptr(residual), res_out.data_ptr(), _ptr(norm_weight), epsilon,
+        w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc), _ptr(bias), out.data_ptr(), M, w.N, w.K, w.G,
+        w.tile, _dt(x), ws.data_ptr(), ws.numel(), split_k, _stream()))
+    return out.reshape(x.shape[:-1] + (w.N,)), res_out.reshape(x.shape)
 
 
 def w4a16_dequantize(w: PackedW4) -> torch.Tensor:
@@ -124,7 +154,7 @@ def w4a16_dequantize(w: PackedW4) -> torch.Tensor:
     _need_cuda(w.packed)
     out = torch.empty((w.K, w.N), dtype=w.scales.dtype, device=w.packed.device)
     check(_lib.lib().mi355q_w4a16_dequantize(w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc),
-                                             out.data_ptr(), w.K, w.N, w.G, _dt(w.scales), _stream()))
+                                             out.data_ptr(), w.K, w.N, w.G, w.tile, _dt(w.scales), _stream()))
     return out
 
 
@@ -288,6 +318,24 @@ def paged_prefill_attention(out, exp_sum, max_logits, tmp_out, query, key_cache,
         key_cache.data_ptr(), value_cache.data_ptr(), key_cache.stride(0), key_cache.stride(1), S, H,
         num_kv_heads, D, scale, block_tables.data_ptr(), block_tables.shape[1], seq_lens.data_ptr(),
         query_start_loc.data_ptr(), max_query_len, block_size, max_seq_len, _ptr(alibi_slopes), _dt(query),
+        int(_is_fp8(kv_cache_dtype)), _ptr(k_scale), _ptr(v_scale), _stream()))
+
+
+def decode_attention_fused(out, exp_sum, max_logits, tmp_out, qkv, positions, cos_sin_cache, key_cache, value_cache,
+                           num_heads: int, num_kv_heads: int, head_size: int, scale: float, block_tables, seq_lens,
+                           block_size: int, max_seq_len: int, kv_cache_dtype: str, k_scale, v_scale) -> None:
+    """rotary_embedding + reshape_and_cache + paged_attention_rocm of one decode step in one
+    launch (the sequence of vllm/v1/attention/backends/rocm_attn.py:367-517).  qkv [S, (H+2KVH)*D]
+    is read only; the new key/value land in the cache at position seq_lens - 1."""
+    _need_cuda(out, qkv, key_cache, value_cache, block_tables, seq_lens, positions, cos_sin_cache)
+    if cos_sin_cache.dtype != qkv.dtype or cos_sin_cache.shape[1] != head_size:
+        raise RuntimeError("decode_attention_fused: cos_sin_cache must be [max_pos, head_size] in the activation dtype")
+    S = qkv.shape[0]
+    check(_lib.lib().mi355q_decode_attention_fused(
+        out.data_ptr(), _ptr(exp_sum), _ptr(max_logits), _ptr(tmp_out), qkv.data_ptr(), qkv.stride(0),
+        positions.data_ptr(), cos_sin_cache.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+        key_cache.stride(0), key_cache.stride(1), S, num_heads, num_kv_heads, head_size, scale,
+        block_tables.data_ptr(), block_tables.shape[1], seq_lens.data_ptr(), block_size, max_seq_len, _dt(qkv),
         int(_is_fp8(kv_cache_dtype)), _ptr(k_scale), _ptr(v_scale), _stream()))
 
 
