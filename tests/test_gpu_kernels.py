@@ -13,6 +13,13 @@ DEV = "cuda:0"
 TDT = {orc.BF16: torch.bfloat16, orc.FP16: torch.float16}
 
 
+@pytest.fixture(autouse=True)
+def _kernel_route(monkeypatch):
+    """These tests check the skinny W4A16 kernel itself at every M; the dequantise + dense GEMM
+    route for long prompts has its own test below."""
+    monkeypatch.setattr(ops, "DEQUANT_MATMUL_MIN_TOKENS", 1 << 30)
+
+
 def to_dev(bits, dt=orc.BF16):
     return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(TDT[dt]).to(DEV)
 
@@ -90,6 +97,24 @@ def test_w4a16_vs_oracle(M, K, N, G, split):
     # run-to-run determinism (no atomics in the split-K path)
     out2 = ops.w4a16_gemm(to_dev(a), w, bias=to_dev(bias), split_k=split)
     assert torch.equal(out, out2)
+
+
+def test_w4a16_many_token_route_vs_oracle(monkeypatch):
+    """Above the token threshold the weight is dequantised to 16-bit and fed to a dense GEMM
+    (exllama reconstruct route, csrc/quantization/gptq/q_gemm.cu:1509-1522): compare with the
+    oracle's rounded-weight GEMM at the reference test tolerance (test_triton_w4a16.py:162)."""
+    monkeypatch.setattr(ops, "DEQUANT_MATMUL_MIN_TOKENS", 32)
+    rng = np.random.default_rng(11)
+    M, K, N, G = 96, 1024, 384, 128
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    a = orc.f32_to_h16(0.25 * rng.standard_normal((M, K)).astype(np.float32))
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N))).astype(np.float32))
+    bias = orc.f32_to_h16(rng.standard_normal(N).astype(np.float32))
+    qw = orc.gptq_pack(q)
+    ref = orc.w4a16_gemm(a, qw, s, None, bias, G=G, round_weight=True)
+    w = ops.w4a16_repack(i32(qw), to_dev(s), None, G)
+    out = ops.w4a16_gemm(to_dev(a), w, bias=to_dev(bias))
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=1e-2)
 
 
 def test_w4a16_split_k_invariance_of_argmax():

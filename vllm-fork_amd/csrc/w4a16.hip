@@ -628,7 +628,8 @@ static Plan make_plan(int M, int N, int K, int G, int sw, bool lds_prologue, int
     while (s < chunks && (size_t)((chunks + s - 1) / s) * act_bytes_per_chunk(CS, M) > ACT_LDS_LIMIT) s++;
   if (!counters_fit(M, N, sw)) s = 1;
   const int per_block = (chunks + s - 1) / s;
-  int nw = ((long)strips * mts * s >= 768 || sw == 64) ? 8 : 16;
+  // 16 waves only pay off when every wave still gets several chunks of a long K
+  int nw = (per_block >= 64 && sw != 64) ? 16 : 8;
   const char* envw = getenv("MI355Q_WAVES");
   if (envw && atoi(envw) > 0) nw = std::min(sw == 64 ? 8 : 16, atoi(envw));
   while (nw > 4 && nw / 2 >= per_block) nw /= 2;

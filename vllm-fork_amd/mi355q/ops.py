@@ -84,6 +84,7 @@ def w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tens
 
 
 _WS: dict = {}
+DEQUANT_MATMUL_MIN_TOKENS = 32
 
 
 def _workspace(dev, nbytes: int) -> torch.Tensor:
@@ -115,6 +116,17 @@ def w4a16_gemm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, s
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     M = x2.shape[0]
+    if M > DEQUANT_MATMUL_MIN_TOKENS and not torch.cuda.is_current_stream_capturing():
+        # many tokens (prompt processing): dequantise once and run a dense GEMM, as the reference
+        # does from 256 tokens on (auto_awq.py:947-955; exllama reconstruct path q_gemm.cu:1509-1522)
+        if fuse_silu_mul:
+            act = torch.empty((M, w.K), dtype=x.dtype, device=x.device)
+            silu_and_mul(act, x2.contiguous())
+            x2 = act
+        out = torch.matmul(x2, w4a16_dequantize(w))
+        if bias is not None:
+            out.add_(bias)
+        return out.reshape(x.shape[:-1] + (w.N,))
     out = torch.empty((M, w.N), dtype=x.dtype, device=x.device)
     L = _lib.lib()
     ws_bytes = L.mi355q_w4a16_workspace_bytes(M, w.N, w.K, w.G)
