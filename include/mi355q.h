@@ -67,7 +67,10 @@ int mi355q_w4a16_choose_tile(int K, int N, int G);
 
 /*
  * Load-time repack of a 4-bit checkpoint tensor into the kernel's tiled layout
- * (1 KiB tiles of `tile` output channels x 2048/tile input channels).
+ * (1 KiB tiles of `tile` output channels x 2048/tile input channels, tiles of one
+ * `tile`-wide strip contiguous along K; within a tile lane l of a 64-lane wavefront
+ * owns 16 bytes = the MFMA B-operand fragments it will feed, so a wavefront reads
+ * one tile with a single coalesced 16-byte-per-lane load).
  * Replaces MPLinearKernel.process_weights_after_loading
  * (mixed_precision/MPLinearKernel.py:56-58; triton_w4a16.py:338-426;
  * exllama.py:60-136 + gptq_shuffle q_gemm.cu:1857-1868).

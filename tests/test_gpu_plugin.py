@@ -1,0 +1,276 @@
+"""The plug-in surface end to end on the GPU: checkpoint tensors -> weight_loader ->
+process_weights_after_loading -> quant_method.apply, the attention layer/backend, the layer
+wrappers, the sampler and the dispatcher ops, each checked against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from mi355q import ops
+from mi355q.plugin import AutoAWQConfig, AutoGPTQConfig, register
+from mi355q.plugin.attention import (Attention, CommonAttentionMetadata, Mi355AttentionBackend,
+                                     Mi355AttentionMetadataBuilder)
+from mi355q.plugin.layers import RMSNorm, SiluAndMul, get_rope
+from mi355q.plugin.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+from mi355q.plugin.sampler import Sampler, SamplingMetadata
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def to_dev(bits, dt=torch.bfloat16):
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(dt).to(DEV)
+
+
+def to_bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def f32(bits, dt=orc.BF16):
+    return orc.h16_to_f32(bits, dt)
+
+
+@pytest.fixture(autouse=True)
+def _kernel_route(monkeypatch):
+    monkeypatch.setattr(ops, "DEQUANT_MATMUL_MIN_TOKENS", 1 << 30)
+
+
+def test_gptq_linear_methods_match_oracle():
+    rng = np.random.default_rng(0)
+    hidden, inter, G, T = 512, 1024, 128, 5
+    cfg = AutoGPTQConfig.from_config({"bits": 4, "group_size": G, "desc_act": False, "sym": True})
+    with torch.device(DEV):   # parameters are created on the device, as vLLM's model loader does
+        gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16,
+                                        quant_config=cfg, prefix="mlp.gate_up_proj", return_bias=False)
+        down = RowParallelLinear(inter, hidden, bias=True, params_dtype=torch.bfloat16, quant_config=cfg,
+                                 prefix="mlp.down_proj", return_bias=False)
+    ck = {}
+    for name, (K, N) in {"gate": (hidden, inter), "up": (hidden, inter), "down": (inter, hidden)}.items():
+        ck[name] = (rng.integers(0, 16, size=(K, N), dtype=np.int32),
+                    orc.f32_to_h16((0.02 * rng.random((K // G, N)) + 0.005).astype(np.float32)))
+    bias = orc.f32_to_h16(rng.standard_normal(hidden).astype(np.float32))
+    for i, n in enumerate(("gate", "up")):
+        gu.weight_loader(gu.qweight, torch.from_numpy(orc.gptq_pack(ck[n][0])), i)
+        gu.weight_loader(gu.scales, to_dev(ck[n][1]).cpu(), i)
+    down.weight_loader(down.qweight, torch.from_numpy(orc.gptq_pack(ck["down"][0])))
+    down.weight_loader(down.scales, to_dev(ck["down"][1]).cpu())
+    down.weight_loader(down.bias, to_dev(bias).cpu())
+    gu.process_weights_after_loading()
+    down.process_weights_after_loading()
+    assert gu.qweight.is_cuda and gu.mi355q_weight.packed.data_ptr() == gu.qweight.data_ptr()
+
+    x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    g = orc.w4a16_gemm(x, orc.gptq_pack(ck["gate"][0]), ck["gate"][1], None, None, G=G)
+    u = orc.w4a16_gemm(x, orc.gptq_pack(ck["up"][0]), ck["up"][1], None, None, G=G)
+    ref_gu = np.concatenate([g, u], axis=1)
+    got_gu = gu(to_dev(x))
+    assert (to_bits(got_gu) == ref_gu).mean() > 0.98
+    np.testing.assert_allclose(f32(to_bits(got_gu)), f32(ref_gu), rtol=1e-2, atol=1e-2)
+    act = SiluAndMul()(got_gu)
+    ref_act = orc.silu_and_mul(to_bits(got_gu))
+    assert np.array_equal(to_bits(act), ref_act)
+    ref = orc.w4a16_gemm(ref_act, orc.gptq_pack(ck["down"][0]), ck["down"][1], None, bias, G=G)
+    got = down(act)
+    np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=1e-2)
+    assert (to_bits(got) == ref).mean() > 0.98
+    # the fused prologue route of the kernel object gives the same numbers as SiluAndMul + apply
+    fused = down.quant_method.kernel.apply_weights_silu_mul(down, got_gu, down.bias)
+    np.testing.assert_allclose(f32(to_bits(fused)), f32(ref), rtol=1e-2, atol=1e-2)
+
+
+def test_awq_linear_method_matches_oracle():
+    rng = np.random.default_rng(1)
+    K, N, G, T = 512, 768, 128, 3
+    cfg = AutoAWQConfig.from_config({"w_bit": 4, "q_group_size": G, "zero_point": True})
+    with torch.device(DEV):
+        lin = RowParallelLinear(K, N, bias=False, params_dtype=torch.float16, quant_config=cfg, prefix="o_proj",
+                                return_bias=False)
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    z = rng.integers(0, 16, size=(K // G, N), dtype=np.int32)
+    s = orc.f32_to_h16((0.02 * rng.random((K // G, N)) + 0.005).astype(np.float32), orc.FP16)
+    qw, qz = orc.pack_cols(q, awq_order=True), orc.pack_cols(z, awq_order=True)
+    lin.weight_loader(lin.qweight, torch.from_numpy(qw))
+    lin.weight_loader(lin.qzeros, torch.from_numpy(qz))
+    lin.weight_loader(lin.scales, to_dev(s, torch.float16).cpu())
+    lin.process_weights_after_loading()
+    x = orc.f32_to_h16(rng.standard_normal((T, K)).astype(np.float32), orc.FP16)
+    ref = orc.w4a16_gemm(x, qw, s, qz, None, G=G, layout=orc.W_AWQ, zp_mode=orc.ZP_AWQ, dt=orc.FP16)
+    got = lin(to_dev(x, torch.float16))
+    np.testing.assert_allclose(f32(to_bits(got), orc.FP16), f32(ref, orc.FP16), rtol=1e-2, atol=1e-2)
+    # fp16 keeps 3 more mantissa bits than bf16, so fp32 summation-order differences show more often
+    assert (to_bits(got) == ref).mean() > 0.9
+
+
+@pytest.mark.parametrize("kv_dtype", ["auto", "fp8"])
+def test_attention_layer_prefill_then_decode(kv_dtype):
+    """Attention.forward = cache update + attention, driven by backend metadata, for a prompt
+    step followed by a decode step; compared with dense causal attention of the oracle."""
+    rng = np.random.default_rng(3)
+    H, KVH, D, bs, nblk = 8, 2, 128, 16, 32
+    fp8 = kv_dtype == "fp8"
+    lens = [21, 50]
+    S, scale = len(lens), 1.0 / D ** 0.5
+    with torch.device(DEV):
+        attn = Attention(H, D, scale, KVH, cache_dtype=kv_dtype, prefix="model.layers.0.self_attn.attn")
+    ks = vs = 1.0
+    if fp8:   # scales arrive from the checkpoint
+        ks, vs = 1 / 32, 1 / 16
+        attn.k_scale.weight_loader(attn.k_scale, torch.tensor(ks))
+        attn.v_scale.weight_loader(attn.v_scale, torch.tensor([vs]))
+    attn.process_weights_after_loading()
+    assert not hasattr(attn, "k_scale") and abs(attn._k_scale_float - ks) < 1e-9 and attn._v_scale.is_cuda
+    shape = Mi355AttentionBackend.get_kv_cache_shape(nblk, bs, KVH, D)
+    attn.kv_cache = torch.zeros(shape, dtype=torch.uint8 if fp8 else torch.bfloat16, device=DEV)
+    builder = Mi355AttentionMetadataBuilder(bs, DEV)
+    maxb = (max(lens) + 1 + bs - 1) // bs
+    bt = rng.permutation(nblk)[: S * maxb].reshape(S, maxb).astype(np.int32)
+
+    def slots(s, lo, hi):
+        return [int(bt[s, j // bs]) * bs + j % bs for j in range(lo, hi)]
+
+    def dq(bits, sc):
+        if not fp8:
+            return bits
+        return orc.f32_to_h16(orc.e4m3_to_f32(orc.f32_to_e4m3(orc.h16_to_f32(bits) / np.float32(sc))) * np.float32(sc))
+
+    qs = [orc.f32_to_h16(rng.uniform(-1, 1, (L + 1, H, D)).astype(np.float32)) for L in lens]
+    kf = [orc.f32_to_h16(rng.uniform(-1, 1, (L + 1, KVH, D)).astype(np.float32)) for L in lens]
+    vf = [orc.f32_to_h16(rng.uniform(-1, 1, (L + 1, KVH, D)).astype(np.float32)) for L in lens]
+    refs = [orc.prefill_attention(qs[s], dq(kf[s], ks), dq(vf[s], vs), scale) for s in range(S)]
+
+    # prompt step
+    T = sum(lens)
+    md = builder.build(0, CommonAttentionMetadata(
+        query_start_loc=torch.tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), device=DEV),
+        seq_lens=torch.tensor(lens, dtype=torch.int32, device=DEV), num_actual_tokens=T, max_query_len=max(lens),
+        max_seq_len=max(lens), block_table_tensor=torch.from_numpy(bt).to(DEV),
+        slot_mapping=torch.tensor(sum((slots(s, 0, lens[s]) for s in range(S)), []), dtype=torch.int64, device=DEV)))
+    q = to_dev(np.concatenate([qs[s][: lens[s]] for s in range(S)])).view(T, H * D)
+    k = to_dev(np.concatenate([kf[s][: lens[s]] for s in range(S)])).view(T, KVH * D)
+    v = to_dev(np.concatenate([vf[s][: lens[s]] for s in range(S)])).view(T, KVH * D)
+    out = attn(q, k, v, md)
+    ref = np.concatenate([refs[s][: lens[s]] for s in range(S)]).reshape(T, H * D)
+    atol = 1e-2 if fp8 else 2e-3
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-5, atol=atol)
+
+    # decode step
+    md = builder.build(0, CommonAttentionMetadata(
+        query_start_loc=torch.arange(S + 1, dtype=torch.int32, device=DEV),
+        seq_lens=torch.tensor([L + 1 for L in lens], dtype=torch.int32, device=DEV), num_actual_tokens=S,
+        max_query_len=1, max_seq_len=max(lens) + 1, block_table_tensor=torch.from_numpy(bt).to(DEV),
+        slot_mapping=torch.tensor([slots(s, lens[s], lens[s] + 1)[0] for s in range(S)], dtype=torch.int64, device=DEV)))
+    q = to_dev(np.stack([qs[s][lens[s]] for s in range(S)])).view(S, H * D)
+    k = to_dev(np.stack([kf[s][lens[s]] for s in range(S)])).view(S, KVH * D)
+    v = to_dev(np.stack([vf[s][lens[s]] for s in range(S)])).view(S, KVH * D)
+    out = attn(q, k, v, md)
+    ref = np.stack([refs[s][lens[s]] for s in range(S)]).reshape(S, H * D)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-5, atol=atol)
+    # memory-profiling call
+    assert float(attn.impl.forward(attn, q, k, v, attn.kv_cache, None, out.clone()).abs().sum()) == 0.0
+
+
+def test_layer_wrappers_match_oracle():
+    rng = np.random.default_rng(4)
+    T, hidden, D, H, KVH = 6, 1024, 128, 4, 2
+    x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    r = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    w = orc.f32_to_h16((1 + 0.1 * rng.standard_normal(hidden)).astype(np.float32))
+    norm = RMSNorm(hidden, eps=1e-5, dtype=torch.bfloat16).to(DEV)
+    norm.weight.data.copy_(to_dev(w))
+    assert np.array_equal(to_bits(norm(to_dev(x))), orc.rms_norm(x, w, 1e-5))
+    xo, ro = norm(to_dev(x), to_dev(r))
+    ref_x, ref_r = orc.fused_add_rms_norm(x, r, w, 1e-5)
+    assert np.array_equal(to_bits(xo), ref_x) and np.array_equal(to_bits(ro), ref_r)
+
+    rope = get_rope(D, 512, True, {"rope_theta": 500000.0, "rope_type": "llama3", "factor": 8.0,
+                                   "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                   "original_max_position_embeddings": 128}, dtype=torch.bfloat16)
+    plain = get_rope(D, 512, True, {"rope_theta": 500000.0}, dtype=torch.bfloat16)
+    # highest frequency untouched, lowest divided by the factor
+    inv_l3, inv = rope._compute_inv_freq(rope.base), plain._compute_inv_freq(plain.base)
+    assert inv_l3[0] == inv[0] and abs(float(inv_l3[-1] / inv[-1]) - 1 / 8) < 1e-6
+    pos = rng.integers(0, 512, size=T).astype(np.int64)
+    q = orc.f32_to_h16(rng.standard_normal((T, H * D)).astype(np.float32))
+    k = orc.f32_to_h16(rng.standard_normal((T, KVH * D)).astype(np.float32))
+    cache = to_bits(rope.cos_sin_cache)
+    ref_q, ref_k = orc.rotary_embedding(pos, q, k, cache, D, True)
+    qd, kd = rope(torch.from_numpy(pos).to(DEV), to_dev(q), to_dev(k))
+    assert np.array_equal(to_bits(qd), ref_q) and np.array_equal(to_bits(kd), ref_k)
+
+
+def test_sampler_greedy_penalties_and_random():
+    rng = np.random.default_rng(5)
+    B, V = 4, 4096
+    logits = orc.f32_to_h16((3 * rng.standard_normal((B, V))).astype(np.float32))
+    logits[1, 77] = logits[1, 4000] = orc.f32_to_h16(np.float32([50.0]))[0]   # tie: first index wins
+    sampler = Sampler()
+    out = sampler(to_dev(logits), SamplingMetadata())
+    assert out.sampled_token_ids.dtype == torch.int32 and out.sampled_token_ids.shape == (B, 1)
+    assert out.sampled_token_ids.view(-1).tolist() == orc.argmax_h16(logits).tolist()
+    assert out.sampled_token_ids[1, 0] == 77
+    # repetition penalty moves the arg-max off an already generated token
+    lf = orc.h16_to_f32(logits)
+    pm = np.zeros((B, V), dtype=bool)
+    om = np.zeros((B, V), dtype=bool)
+    om[1, 77] = om[1, 4000] = True
+    pen = np.full(B, 100.0, dtype=np.float32)
+    ref = orc.argmax_f32(orc.apply_repetition_penalties(lf.copy(), pm, om, pen))
+    md = SamplingMetadata(no_penalties=False, repetition_penalties=torch.from_numpy(pen).to(DEV),
+                          prompt_mask=torch.from_numpy(pm).to(DEV), output_mask=torch.from_numpy(om).to(DEV))
+    got = sampler(to_dev(logits), md).sampled_token_ids.view(-1).tolist()
+    assert got == ref.tolist() and got[1] not in (77, 4000)
+    # random rows: top_k = 1 must reproduce greedy whatever the noise; greedy rows stay greedy
+    temp = torch.tensor([1.0, 0.0, 0.7, 1.3], device=DEV)
+    md = SamplingMetadata(temperature=temp, all_greedy=False, all_random=False,
+                          top_k=torch.ones(B, dtype=torch.int64, device=DEV), top_p=torch.full((B,), 0.9, device=DEV),
+                          generators={0: torch.Generator(device=DEV).manual_seed(1)})
+    assert sampler(to_dev(logits), md).sampled_token_ids.view(-1).tolist() == orc.argmax_h16(logits).tolist()
+    # top-p: only tokens inside the nucleus are ever drawn
+    md = SamplingMetadata(temperature=torch.ones(B, device=DEV), all_greedy=False, all_random=True,
+                          top_p=torch.full((B,), 0.5, device=DEV))
+    probs = torch.softmax(torch.from_numpy(lf), -1)
+    srt, idx = probs.sort(-1, descending=True)
+    inside = [set(idx[b, : int((srt[b].cumsum(0) < 0.5).sum()) + 1].tolist()) for b in range(B)]
+    for _ in range(5):
+        ids = sampler(to_dev(logits), md).sampled_token_ids.view(-1).tolist()
+        assert all(ids[b] in inside[b] for b in range(B))
+
+
+def test_dispatcher_ops_and_graph_capture():
+    """torch.ops.mi355q.* reach the same kernels, and a captured graph of them replays."""
+    register()
+    rng = np.random.default_rng(6)
+    K, N, G = 512, 256, 128
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    s = orc.f32_to_h16((0.02 * rng.random((K // G, N)) + 0.005).astype(np.float32))
+    w = ops.w4a16_repack(torch.from_numpy(orc.gptq_pack(q)).to(DEV), to_dev(s), None, G)
+    x = to_dev(orc.f32_to_h16(rng.standard_normal((2, K)).astype(np.float32)))
+    direct = ops.w4a16_gemm(x, w)
+    via = torch.ops.mi355q.w4a16_gemm(x, w.packed, w.scales, None, None, K, N, G, w.tile)
+    assert torch.equal(direct, via)
+    assert torch.equal(torch.ops.mi355q.w4a16_dequantize(w.packed, w.scales, None, K, N, G, w.tile), ops.w4a16_dequantize(w))
+    out = torch.empty_like(direct)
+    torch.ops.mi355q.rms_norm(out, direct, None, 1e-5)
+    ref = torch.empty_like(direct)
+    ops.rms_norm(ref, direct, None, 1e-5)
+    assert torch.equal(out, ref)
+    assert torch.equal(torch.ops.mi355q.argmax(direct), ops.argmax(direct))
+    # shape-only fakes
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode() as mode:
+        fx = mode.from_tensor(x)
+        fo = torch.ops.mi355q.w4a16_gemm(fx, mode.from_tensor(w.packed), mode.from_tensor(w.scales), None, None, K, N, G, w.tile)
+        assert fo.shape == (2, N) and fo.dtype == torch.bfloat16
+    g = torch.cuda.CUDAGraph()
+    static_x = x.clone()
+    s0 = torch.cuda.Stream()
+    s0.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s0):
+        torch.ops.mi355q.w4a16_gemm(static_x, w.packed, w.scales, None, None, K, N, G, w.tile)
+    torch.cuda.current_stream().wait_stream(s0)
+    with torch.cuda.graph(g):
+        y = torch.ops.mi355q.w4a16_gemm(static_x, w.packed, w.scales, None, None, K, N, G, w.tile)
+    static_x.copy_(x * 2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ops.w4a16_gemm(x * 2, w))

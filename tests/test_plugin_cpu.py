@@ -1,0 +1,317 @@
+"""Host logic of the plug-in surface (no GPU): registries, checkpoint-config parsing, weight
+creation shapes, tensor-parallel shard loading and the load-time repack.  Patterned on the
+reference's tests/quantization/test_register_quantization_config.py, test_auto_gptq.py and
+tests/kernels/quantization/test_mixed_precision... selection tests."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from mi355q import _lib
+from mi355q.plugin import (AutoAWQConfig, AutoGPTQConfig, MI355XW4A16LinearKernel, MPLinearLayerConfig,
+                           choose_mp_linear_kernel, get_quantization_config, register_quantization_config,
+                           resolve_quantization)
+from mi355q.plugin import parallel
+from mi355q.plugin.gptq import get_dynamic_override
+from mi355q.plugin.linear import (ColumnParallelLinear, MergedColumnParallelLinear, QKVParallelLinear,
+                                  RowParallelLinear, UnquantizedLinearMethod)
+from mi355q.plugin.registry import QuantizationConfig
+from mi355q.plugin.scalar_type import scalar_types
+
+GPTQ_CFG = {"quant_method": "gptq", "bits": 4, "group_size": 128, "desc_act": False, "sym": True}
+AWQ_CFG = {"quant_method": "awq", "w_bit": 4, "q_group_size": 128, "zero_point": True, "version": "gemm"}
+
+
+@pytest.fixture
+def tp():
+    """Pretend to be rank r of n without a process group (the loaders only read rank and size)."""
+    def _set(rank, size):
+        parallel._STATE.update(rank=rank, size=size, group=None)
+    yield _set
+    parallel._STATE.update(rank=0, size=1, group=None)
+
+
+# ---------------------------------------------------------------------------
+# registries and config parsing
+# ---------------------------------------------------------------------------
+def test_scalar_types():
+    t = scalar_types.uint4b8
+    assert (t.size_bits, t.bias, t.min(), t.max(), str(t)) == (4, 8, -8, 7, "uint4b8")
+    assert scalar_types.uint4.max() == 15 and not scalar_types.uint4.has_bias()
+    assert scalar_types.uint8b128.size_bits == 8 and scalar_types.uint4b8.id != scalar_types.uint4.id
+
+
+def test_registry_lookup_and_override():
+    assert get_quantization_config("auto_gptq") is AutoGPTQConfig
+    assert get_quantization_config("auto_awq") is AutoAWQConfig
+    with pytest.raises(ValueError, match="Invalid quantization method"):
+        get_quantization_config("no_such_method")
+    with pytest.raises(ValueError, match="subclass"):
+        register_quantization_config("bad")(dict)
+
+    @register_quantization_config("custom_quant")
+    class Custom(AutoGPTQConfig):
+        pass
+
+    assert get_quantization_config("custom_quant") is Custom
+    # re-registering a name swaps the class in
+    register_quantization_config("custom_quant")(AutoGPTQConfig)
+    assert get_quantization_config("custom_quant") is AutoGPTQConfig
+
+
+def test_resolve_quantization_from_checkpoint_config():
+    assert resolve_quantization(GPTQ_CFG) == "auto_gptq"
+    assert resolve_quantization(GPTQ_CFG, "gptq_marlin") == "auto_gptq"
+    assert resolve_quantization(AWQ_CFG) == "auto_awq"
+    with pytest.raises(ValueError, match="Unknown quantization"):
+        resolve_quantization({"quant_method": "nope"})
+
+
+def test_gptq_config_parsing():
+    c = AutoGPTQConfig.from_config(dict(GPTQ_CFG, lm_head=True))
+    assert (c.weight_bits, c.group_size, c.desc_act, c.is_sym, c.pack_factor) == (4, 128, False, True, 8)
+    assert c.quant_type == scalar_types.uint4b8 and c.lm_head_quantized
+    assert AutoGPTQConfig.from_config(dict(GPTQ_CFG, bits=8)).quant_type == scalar_types.uint8b128
+    # one group per channel makes act-order meaningless
+    assert AutoGPTQConfig.from_config(dict(GPTQ_CFG, group_size=-1, desc_act=True)).desc_act is False
+    with pytest.raises(ValueError, match="Unsupported quantization config"):
+        AutoGPTQConfig.from_config(dict(GPTQ_CFG, sym=False))
+    with pytest.raises(ValueError, match="Cannot find any of"):
+        AutoGPTQConfig.from_config({"bits": 4})
+    assert AutoGPTQConfig.get_config_filenames() == ["quantize_config.json"]
+
+
+def test_gptq_dynamic_rules_and_module_list():
+    dyn = {r"+:.*\.layers\.1\..*": {"group_size": 64}, r"-:.*\.layers\.2\..*": {}}
+    c = AutoGPTQConfig.from_config(dict(GPTQ_CFG, dynamic=dyn))
+    assert get_dynamic_override(c, "model.layers.1.mlp.down_proj", "group_size", 128) == 64
+    assert get_dynamic_override(c, "model.layers.2.mlp.down_proj") is False
+    assert get_dynamic_override(c, "model.layers.0.mlp.down_proj", "group_size", 128) == 128
+    l1 = RowParallelLinear(512, 256, bias=False, params_dtype=torch.bfloat16, quant_config=c,
+                           prefix="model.layers.1.mlp.down_proj")
+    assert l1.quant_method.quant_config.group_size == 64 and l1.scales.shape == (8, 256)
+    assert c.group_size == 128   # the override lives on a per-layer copy
+    l2 = RowParallelLinear(512, 256, bias=False, params_dtype=torch.bfloat16, quant_config=c,
+                           prefix="model.layers.2.mlp.down_proj")
+    assert isinstance(l2.quant_method, UnquantizedLinearMethod) and l2.weight.shape == (256, 512)
+    # explicit module list: anything not named stays 16-bit; fused modules are judged by their shards
+    c2 = AutoGPTQConfig.from_config(dict(GPTQ_CFG, modules_in_block_to_quantize=[["self_attn.q_proj", "self_attn.k_proj",
+                                                                                  "self_attn.v_proj"]]))
+    c2.packed_modules_mapping = {"qkv_proj": ["q_proj", "k_proj", "v_proj"]}
+    qkv = QKVParallelLinear(256, 64, 4, 2, bias=False, params_dtype=torch.bfloat16, quant_config=c2,
+                            prefix="model.layers.0.self_attn.qkv_proj")
+    assert hasattr(qkv, "qweight")
+    mlp = RowParallelLinear(512, 256, bias=False, params_dtype=torch.bfloat16, quant_config=c2,
+                            prefix="model.layers.0.mlp.down_proj")
+    assert isinstance(mlp.quant_method, UnquantizedLinearMethod)
+    c3 = AutoGPTQConfig.from_config(GPTQ_CFG)
+    c3.maybe_update_config("m", safetensors_metadata={"model.layers.0.mlp.down_proj.qweight": {"dtype": "I32"},
+                                                      "model.layers.0.mlp.down_proj.scales": {"dtype": "F16"},
+                                                      "lm_head.weight": {"dtype": "BF16"}})
+    assert c3.modules_in_block_to_quantize == ["model.layers.0.mlp.down_proj"]
+
+
+def test_awq_config_parsing_and_skip_list():
+    c = AutoAWQConfig.from_config(dict(AWQ_CFG, modules_to_not_convert=["mlp.gate"]))
+    assert (c.weight_bits, c.group_size, c.zero_point, c.pack_factor) == (4, 128, True, 8)
+    assert c.quant_type == scalar_types.uint4 and c.full_config["quant_method"] == "awq"
+    with pytest.raises(ValueError, match="Unsupported num_bits"):
+        AutoAWQConfig.from_config(dict(AWQ_CFG, w_bit=8))
+    skipped = ColumnParallelLinear(256, 128, bias=False, params_dtype=torch.float16, quant_config=c,
+                                   prefix="model.layers.0.mlp.gate")
+    assert isinstance(skipped.quant_method, UnquantizedLinearMethod)
+    lin = ColumnParallelLinear(256, 128, bias=False, params_dtype=torch.float16, quant_config=c,
+                               prefix="model.layers.0.mlp.up_proj")
+    assert lin.qweight.shape == (256, 16) and lin.qzeros.shape == (2, 16) and lin.scales.shape == (2, 128)
+
+
+def test_cache_scale_name_mapping():
+    m = QuantizationConfig.map_cache_scale_name
+    assert m("model.layers.0.self_attn.kv_scale") == "model.layers.0.self_attn.attn.k_scale"
+    assert m("model.layers.0.self_attn.k_proj.k_scale") == "model.layers.0.self_attn.attn.k_scale"
+    assert m("model.layers.0.self_attn.v_scale") == "model.layers.0.self_attn.attn.v_scale"
+    assert m("model.layers.0.self_attn.attn.v_scale") == "model.layers.0.self_attn.attn.v_scale"
+    assert m("model.layers.0.mlp.down_proj.weight") == "model.layers.0.mlp.down_proj.weight"
+
+
+# ---------------------------------------------------------------------------
+# kernel selection
+# ---------------------------------------------------------------------------
+def _kcfg(**kw):
+    base = dict(full_weight_shape=(4096, 6144), partition_weight_shape=(4096, 6144), weight_type=scalar_types.uint4b8,
+                act_type=torch.bfloat16, group_size=128, zero_points=False, has_g_idx=False)
+    base.update(kw)
+    return MPLinearLayerConfig(**base)
+
+
+def test_kernel_selection_and_reasons(monkeypatch):
+    assert choose_mp_linear_kernel(_kcfg()) is MI355XW4A16LinearKernel
+    assert choose_mp_linear_kernel(_kcfg(weight_type=scalar_types.uint4, zero_points=True)) is MI355XW4A16LinearKernel
+    for bad, why in ((dict(has_g_idx=True), "g_idx"), (dict(act_type=torch.float32), "float16/bfloat16"),
+                     (dict(weight_type=scalar_types.uint8b128), "not supported"),
+                     (dict(partition_weight_shape=(4096, 100)), "multiple of 64"),
+                     (dict(group_size=100), "not divisible"), (dict(weight_type=scalar_types.uint4), "zero points")):
+        ok, reason = MI355XW4A16LinearKernel.can_implement(_kcfg(**bad))
+        assert not ok and why in reason
+        with pytest.raises(ValueError, match="Failed to find a kernel"):
+            choose_mp_linear_kernel(_kcfg(**bad))
+    with pytest.raises(ValueError, match="requires capability 95"):
+        choose_mp_linear_kernel(_kcfg(), compute_capability=94)
+    monkeypatch.setenv("VLLM_DISABLED_KERNELS", "MI355XW4A16LinearKernel")
+    with pytest.raises(ValueError, match="disabled by environment variable"):
+        choose_mp_linear_kernel(_kcfg())
+
+
+def test_gptq_create_weights_shapes_llama8b():
+    c = AutoGPTQConfig.from_config(GPTQ_CFG)
+    qkv = QKVParallelLinear(4096, 128, 32, 8, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="qkv_proj")
+    assert qkv.qweight.shape == (512, 6144) and qkv.qweight.dtype == torch.int32
+    assert qkv.scales.shape == (32, 6144) and qkv.qzeros.shape == (32, 768) and qkv.g_idx.shape == (4096,)
+    gu = MergedColumnParallelLinear(4096, [14336, 14336], bias=False, params_dtype=torch.bfloat16, quant_config=c,
+                                    prefix="gate_up_proj")
+    assert gu.qweight.shape == (512, 28672)
+    down = RowParallelLinear(14336, 4096, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="down_proj")
+    assert down.qweight.shape == (1792, 4096) and down.scales.shape == (112, 4096)
+
+
+# ---------------------------------------------------------------------------
+# tensor-parallel shard loading + load-time repack
+# ---------------------------------------------------------------------------
+def _gptq_tensors(rng, K, N, G):
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N)) + 0.01).astype(np.float32))
+    z = rng.integers(0, 16, size=(K // G, N), dtype=np.int32)
+    return q, s, z
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _bf(bits):
+    return _t(bits.view(np.int16)).view(torch.bfloat16)
+
+
+def _unpacked(layer):
+    w = layer.mi355q_weight
+    back = np.empty((w.K, w.N), dtype=np.int32)
+    _lib.check(_lib.lib().mi355q_w4a16_unpack_host(w.packed.data_ptr(), back.ctypes.data, w.K, w.N, w.tile))
+    return back
+
+
+@pytest.mark.parametrize("tp_size", [1, 2, 4])
+def test_gptq_tp_sharding_of_every_layer_kind(tp, tp_size):
+    """Each rank must end up with exactly the rows/columns of the full matrices that the
+    reference's loaders give it (parameter.py:148-230), including the replicated KV heads when
+    there are fewer KV heads than ranks, and the packed tensors must shard on packed units."""
+    rng = np.random.default_rng(5)
+    hidden, head, H, KVH, inter, G = 256, 64, 8, 2, 512, 64
+    c = AutoGPTQConfig.from_config(dict(GPTQ_CFG, group_size=G))
+    full = {n: _gptq_tensors(rng, K, N, G) for n, (K, N) in
+            {"q": (hidden, H * head), "k": (hidden, KVH * head), "v": (hidden, KVH * head),
+             "gate": (hidden, inter), "up": (hidden, inter), "down": (inter, hidden), "o": (H * head, hidden)}.items()}
+
+    def load(layer, name, shard_id=None):
+        q, s, z = full[name]
+        args = () if shard_id is None else (shard_id,)
+        layer.weight_loader(layer.qweight, _t(orc.gptq_pack(q)), *args)
+        layer.weight_loader(layer.scales, _bf(s), *args)
+        layer.weight_loader(layer.qzeros, _t(orc.pack_cols(z)), *args)
+
+    for rank in range(tp_size):
+        tp(rank, tp_size)
+        qkv = QKVParallelLinear(hidden, head, H, KVH, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="qkv")
+        for sid in "qkv":
+            load(qkv, sid, sid)
+        gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16, quant_config=c,
+                                        prefix="gate_up")
+        load(gu, "gate", 0)
+        load(gu, "up", 1)
+        down = RowParallelLinear(inter, hidden, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="down")
+        load(down, "down")
+        o = RowParallelLinear(H * head, hidden, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="o")
+        load(o, "o")
+
+        hq = H // tp_size * head
+        kv_rank = rank // max(tp_size // KVH, 1)
+        hkv = max(KVH // tp_size, 1) * head
+        exp_qkv = np.concatenate([full["q"][0][:, rank * hq:(rank + 1) * hq],
+                                  full["k"][0][:, kv_rank * hkv:(kv_rank + 1) * hkv],
+                                  full["v"][0][:, kv_rank * hkv:(kv_rank + 1) * hkv]], axis=1)
+        exp_qkv_z = np.concatenate([full["q"][2][:, rank * hq:(rank + 1) * hq],
+                                    full["k"][2][:, kv_rank * hkv:(kv_rank + 1) * hkv],
+                                    full["v"][2][:, kv_rank * hkv:(kv_rank + 1) * hkv]], axis=1)
+        assert np.array_equal(orc.unpack_rows(qkv.qweight.data.numpy()), exp_qkv)
+        assert np.array_equal(orc.unpack_cols(qkv.qzeros.data.numpy()), exp_qkv_z)
+        ni = inter // tp_size
+        exp_gu = np.concatenate([full["gate"][0][:, rank * ni:(rank + 1) * ni], full["up"][0][:, rank * ni:(rank + 1) * ni]], axis=1)
+        exp_gu_s = np.concatenate([full["gate"][1][:, rank * ni:(rank + 1) * ni], full["up"][1][:, rank * ni:(rank + 1) * ni]], axis=1)
+        assert np.array_equal(orc.unpack_rows(gu.qweight.data.numpy()), exp_gu)
+        assert np.array_equal(gu.scales.data.view(torch.int16).numpy().view(np.uint16), exp_gu_s)
+        assert np.array_equal(orc.unpack_rows(down.qweight.data.numpy()), full["down"][0][rank * ni:(rank + 1) * ni])
+        gpr = ni // G
+        assert np.array_equal(down.scales.data.view(torch.int16).numpy().view(np.uint16),
+                              full["down"][1][rank * gpr:(rank + 1) * gpr])
+        # load-time repack (host arithmetic here) keeps exactly those values
+        for layer, exp in ((qkv, exp_qkv), (gu, exp_gu), (down, full["down"][0][rank * ni:(rank + 1) * ni])):
+            layer.process_weights_after_loading()
+            assert np.array_equal(_unpacked(layer), exp)
+            assert layer.qweight.dtype == torch.int32 and layer.qweight.dim() == 1
+            assert type(layer.qweight) is torch.nn.Parameter and layer.qzeros is None and layer.w_zc is None
+
+
+def test_fused_on_disk_tensors_are_split(tp):
+    """A checkpoint that already stores qkv / gate_up fused (no shard id) is cut into its
+    logical matrices before sharding (linear.py:1129-1176)."""
+    rng = np.random.default_rng(6)
+    hidden, head, H, KVH, G = 128, 64, 4, 2, 64
+    c = AutoGPTQConfig.from_config(dict(GPTQ_CFG, group_size=G))
+    N = (H + 2 * KVH) * head
+    q, s, z = _gptq_tensors(rng, hidden, N, G)
+    for rank in range(2):
+        tp(rank, 2)
+        qkv = QKVParallelLinear(hidden, head, H, KVH, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="qkv")
+        qkv.weight_loader(qkv.qweight, _t(orc.gptq_pack(q)))
+        qkv.weight_loader(qkv.qzeros, _t(orc.pack_cols(z)))
+        hq, hkv = H // 2 * head, KVH // 2 * head
+        cols = np.r_[rank * hq:(rank + 1) * hq, H * head + rank * hkv:H * head + (rank + 1) * hkv,
+                     (H + KVH) * head + rank * hkv:(H + KVH) * head + (rank + 1) * hkv]
+        assert np.array_equal(orc.unpack_rows(qkv.qweight.data.numpy()), q[:, cols])
+        assert np.array_equal(orc.unpack_cols(qkv.qzeros.data.numpy()), z[:, cols])
+
+
+def test_awq_tp_sharding_and_repack(tp):
+    rng = np.random.default_rng(8)
+    K, N, G = 256, 256, 64
+    c = AutoAWQConfig.from_config(dict(AWQ_CFG, q_group_size=G))
+    q, s, z = _gptq_tensors(rng, K, N, G)
+    qw, qz = orc.pack_cols(q, awq_order=True), orc.pack_cols(z, awq_order=True)
+    for rank in range(2):
+        tp(rank, 2)
+        col = ColumnParallelLinear(K, N, bias=False, params_dtype=torch.float16, quant_config=c, prefix="up_proj")
+        row = RowParallelLinear(K, N, bias=False, params_dtype=torch.float16, quant_config=c, prefix="down_proj")
+        for layer in (col, row):
+            layer.weight_loader(layer.qweight, _t(qw))
+            layer.weight_loader(layer.qzeros, _t(qz))
+            layer.weight_loader(layer.scales, _t(s.view(np.int16)).view(torch.float16))
+            layer.process_weights_after_loading()
+        h = N // 2
+        assert np.array_equal(_unpacked(col), q[:, rank * h:(rank + 1) * h])
+        assert np.array_equal(_unpacked(row), q[rank * (K // 2):(rank + 1) * (K // 2)])
+        # zc = 1024 + z in fp16 (the magic-number bias of the fp16 kernel plus the zero point)
+        zc = orc.h16_to_f32(col.w_zc.data.view(torch.int16).numpy().view(np.uint16), orc.FP16)
+        assert np.array_equal(zc, 1024.0 + z[:, rank * h:(rank + 1) * h])
+
+
+def test_row_parallel_rejects_misaligned_groups(tp):
+    tp(0, 4)
+    c = AutoAWQConfig.from_config(AWQ_CFG)
+    with pytest.raises(ValueError, match="too large tensor parallel size"):
+        RowParallelLinear(256, 128, bias=False, params_dtype=torch.float16, quant_config=c, prefix="down_proj")
+
+
+def test_loader_shape_mismatch_is_an_error():
+    c = AutoGPTQConfig.from_config(GPTQ_CFG)
+    lin = ColumnParallelLinear(256, 128, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="x")
+    with pytest.raises(ValueError, match="does not fit"):
+        lin.weight_loader(lin.qweight, torch.zeros(16, 128, dtype=torch.int32))

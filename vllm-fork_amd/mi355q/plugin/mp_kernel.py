@@ -1,0 +1,223 @@
+"""Mixed-precision (WNA16) linear-kernel contract, the MI355X kernel that implements it, and the
+per-platform kernel list with its chooser.
+
+Mirrors vllm/model_executor/kernels/linear/mixed_precision/MPLinearKernel.py:14-94 (config +
+abstract kernel), kernels/linear/__init__.py:724-794 (choose_mp_linear_kernel: first kernel in
+the platform's list that is not disabled by VLLM_DISABLED_KERNELS, meets the capability and
+can_implement()s the layer; otherwise ValueError listing every reason) and :1091-1137
+(register_linear_kernel appends at lowest priority).
+"""
+import os
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+
+import torch
+
+from .. import _lib, ops
+from .scalar_type import ScalarType, scalar_types
+
+
+@dataclass
+class MPLinearLayerConfig:
+    full_weight_shape: tuple[int, int]       # [in, out] of the unsharded layer
+    partition_weight_shape: tuple[int, int]  # [in, out] on this rank
+    weight_type: ScalarType
+    act_type: torch.dtype
+    group_size: int
+    zero_points: bool
+    has_g_idx: bool
+    out_type: torch.dtype | None = None
+
+
+class MPLinearKernel(ABC):
+    @classmethod
+    @abstractmethod
+    def get_min_capability(cls) -> int: ...
+
+    @classmethod
+    @abstractmethod
+    def can_implement(cls, c: MPLinearLayerConfig) -> tuple[bool, str | None]: ...
+
+    def __init__(self, c: MPLinearLayerConfig, w_q_param_name: str, w_s_param_name: str,
+                 w_zp_param_name: str | None = None, w_gidx_param_name: str | None = None) -> None:
+        ok, why = self.can_implement(c)
+        if not ok:
+            raise ValueError(f"{type(self).__name__} cannot implement this layer: {why}")
+        if c.zero_points and w_zp_param_name is None:
+            raise ValueError("zero_points=True needs the name of the zero-point parameter")
+        if c.has_g_idx and w_gidx_param_name is None:
+            raise ValueError("has_g_idx=True needs the name of the g_idx parameter")
+        self.config = c
+        self.w_q_name, self.w_s_name = w_q_param_name, w_s_param_name
+        self.w_zp_name, self.w_gidx_name = w_zp_param_name, w_gidx_param_name
+
+    @abstractmethod
+    def process_weights_after_loading(self, layer: torch.nn.Module) -> None: ...
+
+    @abstractmethod
+    def apply_weights(self, layer: torch.nn.Module, x: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor: ...
+
+    def _get_weight_params(self, layer):
+        return (getattr(layer, self.w_q_name), getattr(layer, self.w_s_name),
+                getattr(layer, self.w_zp_name or "", None), getattr(layer, self.w_gidx_name or "", None))
+
+
+def _plain(t: torch.Tensor) -> torch.nn.Parameter:
+    return torch.nn.Parameter(t.data if isinstance(t, torch.nn.Parameter) else t, requires_grad=False)
+
+
+def _set_param(layer: torch.nn.Module, name: str, t: torch.Tensor | None) -> None:
+    """Swap in a plain nn.Parameter (the reference's replace_parameter: loader subclasses are
+    dropped once loading is over so that graph capture sees ordinary tensors)."""
+    if name in layer._parameters:
+        del layer._parameters[name]
+    elif hasattr(layer, name):
+        delattr(layer, name)
+    layer.register_parameter(name, None if t is None else _plain(t))
+
+
+class MI355XW4A16LinearKernel(MPLinearKernel):
+    """4-bit weights x 16-bit activations on gfx950 through libmi355q.
+
+    After process_weights_after_loading the layer holds
+      <w_q>  : int32 [K*N/8]   kernel tile layout (ops.w4a16_repack)
+      <w_s>  : act  [K/G, N]   group scales, checkpoint values
+      w_zc   : act  [K/G, N]   (magic bias + zero point) per group, asymmetric formats only
+    and `mi355q_weight`, the ops.PackedW4 view over them that apply_weights passes to the GEMM.
+
+    Accepted checkpoint layouts, told apart by the loader attributes of the parameters:
+      weight  int32 [K/8, N] or [N, K/8], packed along K  (GPTQ, compressed-tensors)
+              int32 [K, N/8], packed along N, sequential nibbles
+      scales  [K/G, N] or [N, K/G]
+      zeros   int32 [K/G, N/8] or [N/8, K/G], sequential nibbles, value z (uint4) --
+              GPTQ's historical z-1 storage and AWQ's nibble order are selected with
+              `zp_mode` / `src_layout` by the linear method that owns the checkpoint format.
+    """
+
+    SUPPORTED_QUANT_TYPES = (scalar_types.uint4b8, scalar_types.uint4)
+
+    def __init__(self, c, w_q_param_name, w_s_param_name, w_zp_param_name=None, w_gidx_param_name=None,
+                 src_layout: int | None = None, zp_mode: int | None = None):
+        super().__init__(c, w_q_param_name, w_s_param_name, w_zp_param_name, w_gidx_param_name)
+        self.src_layout, self.zp_mode = src_layout, zp_mode
+
+    @classmethod
+    def get_min_capability(cls) -> int:
+        return 95  # gfx950
+
+    @classmethod
+    def can_implement(cls, c: MPLinearLayerConfig) -> tuple[bool, str | None]:
+        if c.weight_type not in cls.SUPPORTED_QUANT_TYPES:
+            return False, f"Quant type {c.weight_type} not supported; supported: {list(cls.SUPPORTED_QUANT_TYPES)}"
+        if c.act_type not in (torch.float16, torch.bfloat16):
+            return False, "Only float16/bfloat16 activations are supported"
+        if c.has_g_idx:
+            return False, "Activation reordering (g_idx) is not supported"
+        if c.weight_type == scalar_types.uint4 and not c.zero_points:
+            return False, "uint4 weights need zero points (symmetric checkpoints use uint4b8)"
+        K, N = c.partition_weight_shape
+        G = K if c.group_size == -1 else c.group_size
+        if G <= 0 or K % G:
+            return False, f"Input features {K} not divisible by group size {G}"
+        if K % 32 or G % 32:
+            return False, f"Input features ({K}) and group size ({G}) must be multiples of 32"
+        if N % 64:
+            return False, f"Output features ({N}) must be a multiple of 64"
+        return True, None
+
+    # -- load time ---------------------------------------------------------
+    def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
+        c = self.config
+        K, N = c.partition_weight_shape
+        G = K if c.group_size == -1 else c.group_size
+        w_q, w_s, w_zp, _ = self._get_weight_params(layer)
+
+        q = w_q.data
+        packed_dim = getattr(w_q, "packed_dim", None)
+        in_dim = getattr(w_q, "input_dim", 0)
+        layout = self.src_layout
+        if tuple(q.shape) == (K // 8, N) and (packed_dim is None or packed_dim == in_dim):
+            layout = _lib.W_GPTQ if layout is None else layout
+        elif tuple(q.shape) == (N, K // 8):
+            q, layout = q.t().contiguous(), _lib.W_GPTQ
+        elif tuple(q.shape) == (K, N // 8):
+            layout = _lib.W_NSEQ if layout is None else layout
+        else:
+            raise ValueError(f"{self.w_q_name}: shape {tuple(q.shape)} is none of [K/8,N], [N,K/8], [K,N/8] "
+                             f"for K={K}, N={N}")
+        s = w_s.data
+        if tuple(s.shape) == (N, K // G) and (K // G != N or getattr(w_s, "output_dim", 1) == 0):
+            s = s.t()
+        if tuple(s.shape) != (K // G, N):
+            raise ValueError(f"{self.w_s_name}: shape {tuple(w_s.shape)} != ({K // G}, {N})")
+        zp_mode, z = _lib.ZP_CONST, None
+        if c.zero_points:
+            if w_zp is None:
+                raise ValueError("layer has no zero-point parameter but the config asks for zero points")
+            z = w_zp.data
+            if tuple(z.shape) == (N // 8, K // G) and (K // G != N // 8 or getattr(w_zp, "output_dim", 1) == 0):
+                z = z.t()
+            if tuple(z.shape) != (K // G, N // 8):
+                raise ValueError(f"{self.w_zp_name}: shape {tuple(w_zp.shape)} != ({K // G}, {N // 8})")
+            zp_mode = self.zp_mode if self.zp_mode is not None else _lib.ZP_NSEQ
+        w = ops.w4a16_repack(q.contiguous(), s.contiguous().to(c.act_type), None if z is None else z.contiguous(),
+                             G, layout, zp_mode)
+        _set_param(layer, self.w_q_name, w.packed)
+        _set_param(layer, self.w_s_name, w.scales)
+        if self.w_zp_name is not None:
+            _set_param(layer, self.w_zp_name, None)   # folded into w_zc (or unused: symmetric)
+        if self.w_gidx_name is not None:
+            _set_param(layer, self.w_gidx_name, None)
+        _set_param(layer, "w_zc", w.zc)
+        layer.mi355q_weight = ops.PackedW4(getattr(layer, self.w_q_name).data, getattr(layer, self.w_s_name).data,
+                                           None if w.zc is None else layer.w_zc.data, K, N, G, w.tile)
+
+    # -- run time ----------------------------------------------------------
+    def apply_weights(self, layer, x, bias=None):
+        return ops.w4a16_gemm(x, layer.mi355q_weight, bias=bias)
+
+    def apply_weights_silu_mul(self, layer, x, bias=None):
+        """x = [.., 2K] gate_up output; SiluAndMul runs in the GEMM prologue."""
+        return ops.w4a16_gemm(x, layer.mi355q_weight, bias=bias, fuse_silu_mul=True)
+
+    def apply_weights_add_rms_norm(self, layer, x, residual, norm_weight, epsilon, bias=None):
+        """fused_add_rms_norm(x, residual) then the GEMM; returns (output, new residual)."""
+        return ops.w4a16_gemm_add_rms_norm(x, residual, norm_weight, epsilon, layer.mi355q_weight, bias=bias)
+
+
+# platform name -> ordered kernel classes.  "rocm" is the only platform this package serves.
+_POSSIBLE_KERNELS: dict[str, list[type[MPLinearKernel]]] = {"rocm": [MI355XW4A16LinearKernel]}
+
+
+def register_linear_kernel(kernel_class: type, platform: str = "rocm", kernel_type: str = "mp") -> None:
+    if kernel_type != "mp":
+        raise ValueError(f"Unrecognized kernel type: {kernel_type}")
+    _POSSIBLE_KERNELS.setdefault(platform, []).append(kernel_class)
+
+
+def _device_capability() -> int | None:
+    if not torch.cuda.is_available():
+        return None
+    major, minor = torch.cuda.get_device_capability()
+    return major * 10 + minor
+
+
+def choose_mp_linear_kernel(config: MPLinearLayerConfig, compute_capability: int | None = None,
+                            platform: str = "rocm") -> type[MPLinearKernel]:
+    if compute_capability is None:
+        compute_capability = _device_capability()
+    disabled = {k.strip() for k in os.environ.get("VLLM_DISABLED_KERNELS", "").split(",") if k.strip()}
+    reasons = []
+    for kernel in _POSSIBLE_KERNELS.get(platform, []):
+        if kernel.__name__ in disabled:
+            reasons.append(f" {kernel.__name__} disabled by environment variable")
+            continue
+        if compute_capability is not None and kernel.get_min_capability() > compute_capability:
+            reasons.append(f"{kernel.__name__} requires capability {kernel.get_min_capability()}, current compute "
+                           f" capability is {compute_capability}")
+            continue
+        ok, why = kernel.can_implement(config)
+        if ok:
+            return kernel
+        reasons.append(f" {kernel.__name__} cannot implement due to: {why}")
+    raise ValueError("Failed to find a kernel that can implement the WNA16 linear layer. Reasons: \n" + "\n".join(reasons))
