@@ -158,6 +158,29 @@ int mi355q_w4a16_dequantize(const void* packed, const void* scales, const void* 
                             int K, int N, int G, int tile, int act_dtype, mi355q_stream_t stream);
 
 /* ------------------------------------------------------------------ */
+/* fp8 weight-only (W8A16) linear                                      */
+/* ------------------------------------------------------------------ */
+/*
+ * C[M,N] = A[M,K] * (W * scale)^T (+ bias), fp32 accumulation, bias added in fp32, one
+ * rounding (F.linear semantics).  W is the checkpoint tensor float8_e4m3fn [N, K] (fp8.py:319-322), untouched.
+ * scales (fp32, device):
+ *   block_k >= K (or <= 0): one scale per output channel, [N]            (per-tensor checkpoints
+ *                           expand their per-logical-matrix scales to this at load time)
+ *   otherwise             : [ceil(N/block_n), ceil(K/block_k)] block scales ("weight_scale_inv",
+ *                           fp8.py:337-346), block_k a multiple of 16
+ * The reference has no fp8 weight-only kernel on ROCm (kernels/linear/__init__.py:405-407);
+ * the arithmetic is that of its dequantise-then-linear fallback (fp8.py:433-454) with the
+ * weight kept in fp32 instead of being rounded to bf16.
+ */
+int mi355q_w8a16_gemm(const void* a, int lda, const void* w, const float* scales, const void* bias,
+                      void* c, int M, int N, int K, int block_n, int block_k, int act_dtype,
+                      mi355q_stream_t stream);
+/* out[N,K] (act_dtype) = round(fp8(W) * scale): the weight of the dense-GEMM route for many
+ * tokens (fp8.py:433-454). */
+int mi355q_w8a16_dequantize(const void* w, const float* scales, void* out, int N, int K,
+                            int block_n, int block_k, int act_dtype, mi355q_stream_t stream);
+
+/* ------------------------------------------------------------------ */
 /* Unquantized skinny linear (lm_head, bf16 decode comparator)         */
 /* ------------------------------------------------------------------ */
 /* C[M,N] = A[M,K] * W[N,K]^T (+ bias); M <= 16 per pass.  Replaces

@@ -140,6 +140,29 @@ def w4a16_gemm(a, qw, scales, qz=None, bias=None, G=128, layout=W_GPTQ, zp_mode=
     return c
 
 
+def w8a16_dequant(w, scales, block=None, dt=BF16, round_weight=False):
+    w = np.ascontiguousarray(w, dtype=np.uint8)
+    N, K = w.shape
+    bn, bk = block or (1, K)
+    out = np.empty((N, K), dtype=np.float32)
+    lib().orc_w8a16_dequant(_p(w), _p(np.ascontiguousarray(scales, dtype=np.float32)), _p(out), _i(N), _i(K),
+                            _i(bn), _i(bk), _i(dt), _i(int(round_weight)))
+    return out
+
+
+def w8a16_gemm(a, w, scales, bias=None, block=None, dt=BF16, round_weight=False):
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    w = np.ascontiguousarray(w, dtype=np.uint8)
+    N, K = w.shape
+    M = a.shape[0]
+    assert a.shape[1] == K
+    bn, bk = block or (1, K)
+    c = np.empty((M, N), dtype=np.uint16)
+    lib().orc_w8a16_gemm(_p(a), _p(w), _p(np.ascontiguousarray(scales, dtype=np.float32)), _p(bias), _p(c),
+                         _i(M), _i(N), _i(K), _i(bn), _i(bk), _i(dt), _i(int(round_weight)))
+    return c
+
+
 def cpu_repack_gptq(qw):
     qw = np.ascontiguousarray(qw, dtype=np.int32)
     K, N = qw.shape[0] * 8, qw.shape[1]

@@ -248,13 +248,6 @@ def gen_awq():
 # kernel-order fused variant (csrc/libtorch_stable/layernorm_kernels.cu:133-172:
 # residual sum rounded to the activation dtype before the variance; restated).
 # --------------------------------------------------------------------------
-def _unwrap(op):
-    for attr in ("impls",):
-        if hasattr(op, attr):
-            return getattr(op, attr)["native"].impl_fn
-    return op
-
-
 def _native(op):
     impls = getattr(op, "impls", None)
     if impls is not None and "native" in impls:
@@ -468,12 +461,41 @@ def gen_sampler():
     )
 
 
+def _fp8_fallback_linear(x, weight_fp8, weight_scale, bias):
+    """The dequantise-then-linear route of Fp8LinearMethod.apply (quantization/fp8.py:433-454):
+    weight and scale go to bf16, are multiplied there (per-tensor scalar or per-row vector), and
+    the product feeds a plain linear.  Restated: the branch sits behind VLLM_BATCH_INVARIANT and a
+    kernel object that cannot be constructed without a GPU platform."""
+    w = weight_fp8.to(torch.bfloat16)
+    s = weight_scale.to(torch.bfloat16)
+    w = w * (s if s.numel() == 1 else s.unsqueeze(1))
+    return torch.nn.functional.linear(x, w, bias)
+
+
+def gen_w8a16():
+    torch.manual_seed(0)
+    out, names = {}, []
+    for tag, M, N, K, per_row, with_bias in [("t_m1", 1, 256, 512, False, False), ("t_m3_bias", 3, 192, 1024, False, True),
+                                             ("row_m2", 2, 128, 768, True, False), ("row_m5_bias", 5, 320, 256, True, True)]:
+        w = torch.randn(N, K) * 0.05
+        scale = (w.abs().amax(dim=1) if per_row else w.abs().amax().reshape(1)) / 448.0
+        wq = (w / (scale.unsqueeze(1) if per_row else scale)).to(torch.float8_e4m3fn)
+        x = (torch.randn(M, K) * 0.5).to(torch.bfloat16)
+        bias = torch.randn(N).to(torch.bfloat16) if with_bias else None
+        ref = _fp8_fallback_linear(x, wq, scale, bias)
+        names.append(tag)
+        out[tag + "_w"] = bits8(wq)
+        out[tag + "_scale"] = scale.numpy().astype(np.float32)
+        out[tag + "_x"] = bits16(x)
+        out[tag + "_ref"] = bits16(ref)
+        if with_bias:
+            out[tag + "_bias"] = bits16(bias)
+    save("w8a16", names=np.array(names), restated=np.array([1]), **out)
+
+
+GENERATORS = {"pack": gen_pack, "quantize": gen_quantize, "w4a16": gen_w4a16, "awq": gen_awq, "rmsnorm": gen_rmsnorm,
+              "rope": gen_rope, "paged_attn": gen_paged_attn, "sampler": gen_sampler, "w8a16": gen_w8a16}
+
 if __name__ == "__main__":
-    gen_pack()
-    gen_quantize()
-    gen_w4a16()
-    gen_awq()
-    gen_rmsnorm()
-    gen_rope()
-    gen_paged_attn()
-    gen_sampler()
+    for name in (sys.argv[1:] or GENERATORS):
+        GENERATORS[name]()

@@ -582,3 +582,64 @@ def test_decode_attention_fused_equals_unfused(H, KVH, D, bs, fp8):
     assert torch.equal(kc1.view(torch.uint8), kc2.view(torch.uint8))
     assert torch.equal(vc1.view(torch.uint8), vc2.view(torch.uint8))
     assert torch.equal(o1, o2)
+
+
+# ---------------------------------------------------------------------------
+# fp8 weight-only
+# ---------------------------------------------------------------------------
+def test_w8a16_golden(golden):
+    """Inputs/outputs of the reference's dequantise-then-linear route (fp8.py:433-454); the kernel
+    keeps the weight in fp32, so it agrees to the W4A16 test tolerance (rtol = atol = 1e-2)."""
+    g = golden("w8a16")
+    for tag in g["names"]:
+        tag = str(tag)
+        w = torch.from_numpy(g[tag + "_w"]).to(DEV)
+        N = w.shape[0]
+        scale = torch.from_numpy(np.broadcast_to(g[tag + "_scale"], (N,)).astype(np.float32).copy()).to(DEV)
+        bias = to_dev(g[tag + "_bias"]) if tag + "_bias" in g else None
+        out = ops.w8a16_gemm(to_dev(g[tag + "_x"]), w, scale, None, bias)
+        np.testing.assert_allclose(f32(to_bits(out)), f32(g[tag + "_ref"]), rtol=1e-2, atol=1e-2, err_msg=tag)
+
+
+@pytest.mark.parametrize("M,N,K,block,dt", [(1, 4096, 4096, None, orc.BF16), (3, 1000, 512, None, orc.BF16),
+                                            (4, 384, 1024, (128, 128), orc.BF16), (7, 200, 256, (64, 32), orc.FP16),
+                                            (1, 8192, 14336, (128, 128), orc.BF16), (40, 256, 512, None, orc.BF16)])
+def test_w8a16_vs_oracle(M, N, K, block, dt):
+    rng = np.random.default_rng(N + K)
+    w8 = orc.f32_to_e4m3((rng.standard_normal((N, K)) * 40).astype(np.float32))
+    if block is None:
+        s = (0.001 + 0.002 * rng.random(N)).astype(np.float32)
+    else:
+        s = (0.001 + 0.002 * rng.random(((N + block[0] - 1) // block[0], (K + block[1] - 1) // block[1]))).astype(np.float32)
+    a = orc.f32_to_h16(rng.standard_normal((M, K)).astype(np.float32), dt)
+    bias = orc.f32_to_h16(rng.standard_normal(N).astype(np.float32), dt)
+    ref = orc.w8a16_gemm(a, w8, s, bias, block=block, dt=dt)
+    out = ops.w8a16_gemm(to_dev(a, dt), torch.from_numpy(w8).to(DEV), torch.from_numpy(s).to(DEV), block, to_dev(bias, dt))
+    np.testing.assert_allclose(f32(to_bits(out), dt), f32(ref, dt), rtol=1e-2, atol=1e-2)
+    # fp32 products on both sides (the oracle sums in double): all but rounding ties are bit-equal
+    assert (to_bits(out) == ref).mean() > (0.97 if dt == orc.BF16 else 0.9)
+    deq = ops.w8a16_dequantize(torch.from_numpy(w8).to(DEV), torch.from_numpy(s).to(DEV), block, TDT[dt])
+    assert np.array_equal(to_bits(deq), orc.f32_to_h16(orc.w8a16_dequant(w8, s, block=block, dt=dt), dt))
+
+
+def test_w8a16_many_token_route(monkeypatch):
+    monkeypatch.setattr(ops, "DEQUANT_MATMUL_MIN_TOKENS", 32)
+    rng = np.random.default_rng(2)
+    M, N, K = 64, 256, 512
+    w8 = orc.f32_to_e4m3((rng.standard_normal((N, K)) * 40).astype(np.float32))
+    s = (0.001 + 0.002 * rng.random(N)).astype(np.float32)
+    a = orc.f32_to_h16(rng.standard_normal((M, K)).astype(np.float32))
+    ref = orc.w8a16_gemm(a, w8, s, None, round_weight=2)   # weight rounded to bf16, scale kept in fp32
+    out = ops.w8a16_gemm(to_dev(a), torch.from_numpy(w8).to(DEV), torch.from_numpy(s).to(DEV))
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=1e-2)
+
+
+def test_w8a16_bad_arguments():
+    w = torch.zeros((64, 128), dtype=torch.uint8, device=DEV)
+    x = torch.zeros((1, 128), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="per-channel scales must have 64"):
+        ops.w8a16_gemm(x, w, torch.ones(3, device=DEV))
+    with pytest.raises(RuntimeError, match="block scales shape"):
+        ops.w8a16_gemm(x, w, torch.ones((1, 2), device=DEV), (64, 32))
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        ops.w8a16_gemm(x, w, torch.ones((1, 16), device=DEV), (64, 8))

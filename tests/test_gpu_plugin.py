@@ -274,3 +274,51 @@ def test_dispatcher_ops_and_graph_capture():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, ops.w4a16_gemm(x * 2, w))
+
+
+@pytest.mark.parametrize("block", [None, [128, 128]])
+def test_fp8_weight_only_linear_method(block):
+    from mi355q.plugin import Fp8Config
+    rng = np.random.default_rng(9)
+    hidden, inter, T = 512, 768, 2
+    cfg = Fp8Config(True, "dynamic", weight_block_size=block)
+    with torch.device(DEV):
+        gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16,
+                                        quant_config=cfg, prefix="mlp.gate_up_proj", return_bias=False)
+    ws, ss = [], []
+    for i in range(2):
+        w8 = orc.f32_to_e4m3((rng.standard_normal((inter, hidden)) * 30).astype(np.float32))
+        gu.weight_loader(gu.weight, torch.from_numpy(w8).view(torch.float8_e4m3fn), i)
+        if block is None:
+            s = np.float32(0.002 * (i + 1))
+            gu.weight_loader(gu.weight_scale, torch.tensor(s), i)
+            ss.append(np.full(inter, s, dtype=np.float32))
+        else:
+            s = (0.001 + 0.002 * rng.random((inter // 128, hidden // 128))).astype(np.float32)
+            gu.weight_loader(gu.weight_scale_inv, torch.from_numpy(s), i)
+            ss.append(s)
+        ws.append(w8)
+    gu.process_weights_after_loading()
+    x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    ref = orc.w8a16_gemm(x, np.concatenate(ws), np.concatenate(ss), None, block=None if block is None else tuple(block))
+    got = gu(to_dev(x))
+    np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=1e-2)
+    assert (to_bits(got) == ref).mean() > 0.97
+
+
+def test_fp8_online_quantisation_of_16bit_checkpoint():
+    from mi355q.plugin import Fp8Config
+    rng = np.random.default_rng(10)
+    K, N, T = 256, 128, 3
+    with torch.device(DEV):
+        lin = RowParallelLinear(K, N, bias=False, params_dtype=torch.bfloat16, quant_config=Fp8Config(False, "dynamic"),
+                                prefix="o_proj", return_bias=False)
+    w = torch.from_numpy((rng.standard_normal((N, K)) * 0.05).astype(np.float32)).to(torch.bfloat16)
+    lin.weight_loader(lin.weight, w)
+    lin.process_weights_after_loading()
+    assert lin.weight.dtype == torch.float8_e4m3fn and lin.weight_scale.shape == (N,)
+    x = torch.from_numpy(rng.standard_normal((T, K)).astype(np.float32)).to(torch.bfloat16)
+    ref = torch.nn.functional.linear(x.float(), w.float())
+    got = lin(x.to(DEV)).float().cpu()
+    # e4m3 keeps 3 mantissa bits: relative weight error <= 2^-4, averaged down over K terms
+    assert float((got - ref).abs().max()) < 0.06 * float(ref.abs().max())

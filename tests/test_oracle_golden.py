@@ -169,3 +169,27 @@ def test_h16_codecs_match_torch():
         mine = orc.f32_to_h16(x.numpy(), dt)
         assert np.array_equal(mine, ref.view(torch.int16).numpy().view(np.uint16))
         assert np.array_equal(orc.h16_to_f32(mine, dt), ref.float().numpy())
+
+
+def test_w8a16_fallback_linear(golden):
+    """fp8 weight-only linear: the reference's dequantise-then-linear route
+    (quantization/fp8.py:433-454).  The rounded-weight oracle follows it to the last bf16 ulp
+    of the output (torch's CPU bf16 matmul orders its sums differently); the fp32-weight variant,
+    which the HIP kernel implements, stays within the W4A16 test tolerance of it."""
+    g = golden("w8a16")
+    for tag in g["names"]:
+        tag = str(tag)
+        w, x, ref = g[tag + "_w"], g[tag + "_x"], f32(g[tag + "_ref"])
+        N = w.shape[0]
+        scale = np.broadcast_to(g[tag + "_scale"], (N,)).astype(np.float32)
+        bias = g[tag + "_bias"] if tag + "_bias" in g else None
+        out = f32(orc.w8a16_gemm(x, w, scale, bias, round_weight=True))
+        np.testing.assert_allclose(out, ref, rtol=2 ** -7, atol=2 ** -7, err_msg=tag)
+        assert (out == ref).mean() > 0.9, tag
+        out32 = f32(orc.w8a16_gemm(x, w, scale, bias, round_weight=False))
+        np.testing.assert_allclose(out32, ref, rtol=1e-2, atol=1e-2, err_msg=tag)
+        deq = orc.w8a16_dequant(w, scale, round_weight=True)
+        import torch
+        wt = torch.from_numpy(w).view(torch.float8_e4m3fn).to(torch.bfloat16) * \
+            torch.from_numpy(scale).to(torch.bfloat16).unsqueeze(1)
+        assert np.array_equal(deq, wt.float().numpy()), tag

@@ -315,3 +315,83 @@ def test_loader_shape_mismatch_is_an_error():
     lin = ColumnParallelLinear(256, 128, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="x")
     with pytest.raises(ValueError, match="does not fit"):
         lin.weight_loader(lin.qweight, torch.zeros(16, 128, dtype=torch.int32))
+
+
+# ---------------------------------------------------------------------------
+# fp8 weight-only
+# ---------------------------------------------------------------------------
+def test_fp8_config_parsing():
+    from mi355q.plugin import Fp8Config
+    from mi355q.plugin.fp8 import Fp8LinearMethod, Fp8PerTensorOnlineLinearMethod
+    assert get_quantization_config("fp8") is Fp8Config
+    c = Fp8Config.from_config({"quant_method": "fp8", "activation_scheme": "static", "ignored_layers": ["lm_head"]})
+    assert c.is_checkpoint_fp8_serialized and c.activation_scheme == "static" and c.ignored_layers == ["lm_head"]
+    c = Fp8Config.from_config({"quant_method": "fp8", "activation_scheme": "dynamic", "weight_block_size": [128, 128],
+                               "modules_to_not_convert": ["mlp.gate"]})
+    assert c.weight_block_size == [128, 128] and c.ignored_layers == ["mlp.gate"]
+    with pytest.raises(ValueError, match="Unsupported activation scheme"):
+        Fp8Config(True, "per_token")
+    with pytest.raises(ValueError, match="dynamic activation scheme"):
+        Fp8Config(True, "static", weight_block_size=[128, 128])
+    with pytest.raises(ValueError, match="fp8-serialized"):
+        Fp8Config(False, "dynamic", weight_block_size=[128, 128])
+    lin = ColumnParallelLinear(256, 128, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="mlp.up_proj")
+    assert isinstance(lin.quant_method, Fp8LinearMethod) and lin.weight.dtype == torch.float8_e4m3fn
+    assert lin.weight.shape == (128, 256) and lin.weight_scale_inv.shape == (1, 2)
+    skipped = ColumnParallelLinear(256, 128, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="mlp.gate")
+    assert isinstance(skipped.quant_method, UnquantizedLinearMethod)
+    online = ColumnParallelLinear(256, 128, bias=False, params_dtype=torch.bfloat16,
+                                  quant_config=Fp8Config(False, "dynamic"), prefix="mlp.up_proj")
+    assert isinstance(online.quant_method, Fp8PerTensorOnlineLinearMethod) and online.weight.dtype == torch.bfloat16
+    assert Fp8Config.map_cache_scale_name("model.layers.0.self_attn.k_proj.output_scale") == \
+        "model.layers.0.self_attn.attn.k_scale"
+
+
+def test_fp8_per_tensor_scales_expand_per_channel_and_shard(tp):
+    from mi355q.plugin import Fp8Config
+    c = Fp8Config.from_config({"quant_method": "fp8", "activation_scheme": "static"})
+    rng = np.random.default_rng(3)
+    hidden, head, H, KVH = 128, 64, 4, 2
+    full = {n: torch.from_numpy(rng.integers(0, 120, size=(w, hidden), dtype=np.uint8)).view(torch.float8_e4m3fn)
+            for n, w in (("q", H * head), ("k", KVH * head), ("v", KVH * head))}
+    scales = {"q": 0.5, "k": 0.25, "v": 2.0}
+    for rank in range(2):
+        tp(rank, 2)
+        qkv = QKVParallelLinear(hidden, head, H, KVH, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="qkv")
+        for sid in "qkv":
+            qkv.weight_loader(qkv.weight, full[sid], sid)
+            qkv.weight_loader(qkv.weight_scale, torch.tensor(scales[sid]), sid)
+            qkv.weight_loader(qkv.input_scale, torch.tensor(1.0), sid)
+        qkv.process_weights_after_loading()
+        hq, hkv = H // 2 * head, KVH // 2 * head
+        exp = torch.cat([full["q"].view(torch.uint8)[rank * hq:(rank + 1) * hq],
+                         full["k"].view(torch.uint8)[rank * hkv:(rank + 1) * hkv],
+                         full["v"].view(torch.uint8)[rank * hkv:(rank + 1) * hkv]])
+        assert torch.equal(qkv.weight.data.view(torch.uint8), exp)
+        assert qkv.weight_scale.tolist() == [0.5] * hq + [0.25] * hkv + [2.0] * hkv
+        assert qkv.input_scale is None and qkv.mi355q_scale_block is None
+
+
+def test_fp8_block_scales_shard_on_tiles(tp):
+    from mi355q.plugin import Fp8Config
+    c = Fp8Config.from_config({"quant_method": "fp8", "activation_scheme": "dynamic", "weight_block_size": [64, 32]})
+    rng = np.random.default_rng(4)
+    hidden, inter = 128, 256
+    sg = torch.from_numpy(rng.random((inter // 64, hidden // 32)).astype(np.float32))
+    su = torch.from_numpy(rng.random((inter // 64, hidden // 32)).astype(np.float32))
+    sd = torch.from_numpy(rng.random((hidden // 64, inter // 32)).astype(np.float32))
+    for rank in range(2):
+        tp(rank, 2)
+        gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16, quant_config=c,
+                                        prefix="gate_up")
+        gu.weight_loader(gu.weight_scale_inv, sg, 0)
+        gu.weight_loader(gu.weight_scale_inv, su, 1)
+        assert gu.weight_scale_inv.shape == (4, 4)
+        assert torch.equal(gu.weight_scale_inv.data, torch.cat([sg[rank * 2:(rank + 1) * 2], su[rank * 2:(rank + 1) * 2]]))
+        down = RowParallelLinear(inter, hidden, bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="down")
+        down.weight_loader(down.weight_scale_inv, sd)
+        assert torch.equal(down.weight_scale_inv.data, sd[:, rank * 4:(rank + 1) * 4])
+    tp(0, 4)
+    with pytest.raises(ValueError, match="not divisible by weight quantization block_k"):
+        RowParallelLinear(inter, hidden, bias=False, params_dtype=torch.bfloat16,
+                          quant_config=Fp8Config(True, "dynamic", weight_block_size=[64, 128]), prefix="down")

@@ -1,0 +1,222 @@
+// fp8 (OCP e4m3fn) weight-only linear for decode: C[M,N] = A[M,K] * (W[N,K] * scale)^T with
+// 16-bit activations and fp32 accumulation.  HBM-bound on W (1 byte per weight): every wave
+// streams whole weight rows with 16-byte lane loads (16 weights per lane, 1 KiB contiguous per
+// wave instruction), converts them with the hardware v_cvt_pk_f32_fp8, multiplies against the
+// activations staged in LDS, and a wave64 shuffle tree finishes each row.  Scales are fp32:
+// one per output channel, or one per (block_n x block_k) tile of W for block-quantised
+// checkpoints (then every lane's 16-element partial product is scaled before it is added).
+// The bias joins in fp32 before the single rounding, as in F.linear's GEMM epilogue.
+#include "common.h"
+
+namespace mi355q {
+
+template <typename DT>
+__device__ inline f32x2 unpack2(uint32_t u);
+template <>
+__device__ inline f32x2 unpack2<BF16>(uint32_t u) {
+  f32x2 r;
+  r.x = __builtin_bit_cast(float, u << 16);
+  r.y = __builtin_bit_cast(float, u & 0xffff0000u);
+  return r;
+}
+template <>
+__device__ inline f32x2 unpack2<FP16>(uint32_t u) {
+  f32x2 r;
+  r.x = FP16::to_f32((uint16_t)(u & 0xffffu));
+  r.y = FP16::to_f32((uint16_t)(u >> 16));
+  return r;
+}
+
+// dot product of 16 fp8 weights (one u32x4) with 16 16-bit activations (two u32x4)
+template <typename DT>
+__device__ inline float dot16(u32x4 w, u32x4 x0, u32x4 x1) {
+  f32x2 acc = {0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const f32x2 wl = fp8x2_to_f32(w[e], false), wh = fp8x2_to_f32(w[e], true);
+    const uint32_t xa = e < 2 ? x0[2 * e] : x1[2 * e - 4];
+    const uint32_t xb = e < 2 ? x0[2 * e + 1] : x1[2 * e - 3];
+    acc += wl * unpack2<DT>(xa);
+    acc += wh * unpack2<DT>(xb);
+  }
+  return acc.x + acc.y;
+}
+
+template <typename DT, int MB, bool BLOCK_SCALE>
+__global__ __launch_bounds__(256) void w8a16_skinny_kernel(
+    const uint16_t* __restrict__ a, int lda, const uint8_t* __restrict__ w,
+    const float* __restrict__ scales, const uint16_t* __restrict__ bias, uint16_t* __restrict__ c,
+    int M, int N, int K, int block_n, int block_k, int scale_cols, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* xs = reinterpret_cast<u32x4*>(smem);  // [MB][K/8]
+  constexpr int R = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * MB;
+  const int mb = min(MB, M - m0);
+  const int kv8 = K >> 3;   // 16-byte activation vectors per row
+  const int kv16 = K >> 4;  // 16-byte weight vectors per row
+
+  for (int idx = threadIdx.x; idx < MB * kv8; idx += 256) {
+    const int m = idx / kv8, v = idx - m * kv8;
+    const int mr = m0 + min(m, mb - 1);
+    xs[idx] = reinterpret_cast<const u32x4*>(a + (size_t)mr * lda)[v];
+  }
+  __syncthreads();
+
+  const int n_begin = blockIdx.x * rows_per_block;
+  const int n_end = min(N, n_begin + rows_per_block);
+  for (int n = n_begin + wave * R; n < n_end; n += 4 * R) {
+    float acc[R][MB];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int m = 0; m < MB; m++) acc[r][m] = 0.f;
+    const bool has1 = n + 1 < n_end;
+    const int n1 = has1 ? n + 1 : n;
+    const u32x4* w0 = reinterpret_cast<const u32x4*>(w + (size_t)n * K);
+    const u32x4* w1 = reinterpret_cast<const u32x4*>(w + (size_t)n1 * K);
+    const float* s0 = scales + (size_t)(BLOCK_SCALE ? n / block_n : n) * scale_cols;
+    const float* s1 = scales + (size_t)(BLOCK_SCALE ? n1 / block_n : n1) * scale_cols;
+#pragma unroll 2
+    for (int v = lane; v < kv16; v += 64) {
+      const u32x4 wa = __builtin_nontemporal_load(w0 + v);
+      const u32x4 wb = __builtin_nontemporal_load(w1 + v);
+      float sa = 1.f, sb = 1.f;
+      if (BLOCK_SCALE) {
+        const int kb = (v << 4) / block_k;
+        sa = s0[kb];
+        sb = s1[kb];
+      }
+#pragma unroll
+      for (int m = 0; m < MB; m++) {
+        const u32x4 x0 = xs[m * kv8 + 2 * v], x1 = xs[m * kv8 + 2 * v + 1];
+        if (BLOCK_SCALE) {
+          acc[0][m] += sa * dot16<DT>(wa, x0, x1);
+          acc[1][m] += sb * dot16<DT>(wb, x0, x1);
+        } else {
+          acc[0][m] += dot16<DT>(wa, x0, x1);
+          acc[1][m] += dot16<DT>(wb, x0, x1);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int m = 0; m < MB; m++) acc[r][m] = wave_sum(acc[r][m]);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (r == 1 && !has1) break;
+        const float s = BLOCK_SCALE ? 1.f : (r == 0 ? s0[0] : s1[0]);
+        const float b = bias ? DT::to_f32(bias[n + r]) : 0.f;
+#pragma unroll
+        for (int m = 0; m < MB; m++)
+          if (m < mb) c[(size_t)(m0 + m) * N + n + r] = DT::from_f32(acc[r][m] * s + b);
+      }
+    }
+  }
+}
+
+// W16[N,K] = round(fp8(W) * scale): the weight the dense-GEMM route multiplies with.
+template <typename DT>
+__global__ __launch_bounds__(256) void w8a16_dequantize_kernel(const uint8_t* __restrict__ w,
+                                                               const float* __restrict__ scales,
+                                                               uint16_t* __restrict__ out, int N, int K,
+                                                               int block_n, int block_k, int scale_cols) {
+  const size_t vec = (size_t)blockIdx.x * 256 + threadIdx.x;  // 4 weights per thread
+  const size_t total = (size_t)N * K / 4;
+  if (vec >= total) return;
+  const size_t e = vec * 4;
+  const int n = (int)(e / K), k = (int)(e - (size_t)n * K);
+  const float s = scales[(size_t)(n / block_n) * scale_cols + k / block_k];
+  const uint32_t p = reinterpret_cast<const uint32_t*>(w)[vec];
+  const f32x2 lo = fp8x2_to_f32(p, false), hi = fp8x2_to_f32(p, true);
+  u32x2 o;
+  o.x = pack2<DT>(lo.x * s, lo.y * s);
+  o.y = pack2<DT>(hi.x * s, hi.y * s);
+  reinterpret_cast<u32x2*>(out)[vec] = o;
+}
+
+template <typename DT>
+static int launch_w8a16(const void* a, int lda, const void* w, const float* scales, const void* bias,
+                        void* c, int M, int N, int K, int block_n, int block_k, hipStream_t stream) {
+  const bool block_scale = block_k < K;
+  const int scale_cols = block_scale ? (K + block_k - 1) / block_k : 1;
+  int MB = M >= 4 ? 4 : (M >= 2 ? 2 : 1);
+  while (MB > 1 && (size_t)MB * K * 2 > 64 * 1024) MB >>= 1;
+  const size_t lds = (size_t)MB * K * 2;
+  MI355Q_REQUIRE(lds <= 64 * 1024, "w8a16_gemm: K=%d too large for one LDS pass", K);
+  int rows_per_block = 64;
+  while (rows_per_block > 8 && (N + rows_per_block - 1) / rows_per_block < 2048) rows_per_block >>= 1;
+  dim3 grid((N + rows_per_block - 1) / rows_per_block, (M + MB - 1) / MB), block(256);
+#define MI355Q_W8(mb, bs)                                                                          \
+  hipLaunchKernelGGL((w8a16_skinny_kernel<DT, mb, bs>), grid, block, lds, stream,                  \
+                     (const uint16_t*)a, lda, (const uint8_t*)w, scales, (const uint16_t*)bias,    \
+                     (uint16_t*)c, M, N, K, block_scale ? block_n : 1, block_k, scale_cols,        \
+                     rows_per_block)
+  if (block_scale) {
+    switch (MB) {
+      case 4: MI355Q_W8(4, true); break;
+      case 2: MI355Q_W8(2, true); break;
+      default: MI355Q_W8(1, true); break;
+    }
+  } else {
+    switch (MB) {
+      case 4: MI355Q_W8(4, false); break;
+      case 2: MI355Q_W8(2, false); break;
+      default: MI355Q_W8(1, false); break;
+    }
+  }
+#undef MI355Q_W8
+  return check_launch("w8a16_skinny_kernel");
+}
+
+static int check_w8_scales(const char* who, int N, int K, int block_n, int block_k) {
+  MI355Q_REQUIRE(block_n >= 1 && block_k >= 16 && block_k % 16 == 0,
+                 "%s: scale block (%d, %d) must be >= (1, 16) with block_k a multiple of 16", who, block_n, block_k);
+  MI355Q_REQUIRE(block_k < K || block_n == 1,
+                 "%s: a scale that spans all of K must be per output channel (block_n == 1), got block_n=%d",
+                 who, block_n);
+  (void)N;
+  return MI355Q_OK;
+}
+
+}  // namespace mi355q
+
+using namespace mi355q;
+
+extern "C" int mi355q_w8a16_gemm(const void* a, int lda, const void* w, const float* scales,
+                                 const void* bias, void* c, int M, int N, int K, int block_n,
+                                 int block_k, int act_dtype, mi355q_stream_t stream) {
+  MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w8a16_gemm: dtype must be bf16 or fp16");
+  if (M == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(a && w && scales && c && N > 0 && K > 0 && M >= 0, "w8a16_gemm: bad arguments");
+  MI355Q_REQUIRE(K % 16 == 0 && lda % 8 == 0 && lda >= K, "w8a16_gemm: K=%d must be a multiple of 16 and lda=%d of 8", K, lda);
+  MI355Q_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, "w8a16_gemm: pointers must be 16-byte aligned");
+  if (block_k <= 0 || block_k > K) block_k = K;
+  if (block_n <= 0) block_n = 1;
+  if (int st = check_w8_scales("w8a16_gemm", N, K, block_n, block_k)) return st;
+  if (act_dtype == MI355Q_BF16)
+    return launch_w8a16<BF16>(a, lda, w, scales, bias, c, M, N, K, block_n, block_k, (hipStream_t)stream);
+  return launch_w8a16<FP16>(a, lda, w, scales, bias, c, M, N, K, block_n, block_k, (hipStream_t)stream);
+}
+
+extern "C" int mi355q_w8a16_dequantize(const void* w, const float* scales, void* out, int N, int K,
+                                       int block_n, int block_k, int act_dtype,
+                                       mi355q_stream_t stream) {
+  MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w8a16_dequantize: dtype must be bf16 or fp16");
+  MI355Q_REQUIRE(w && scales && out && N > 0 && K > 0 && K % 16 == 0, "w8a16_dequantize: bad arguments");
+  if (block_k <= 0 || block_k > K) block_k = K;
+  if (block_n <= 0) block_n = 1;
+  if (int st = check_w8_scales("w8a16_dequantize", N, K, block_n, block_k)) return st;
+  const int scale_cols = (K + block_k - 1) / block_k;
+  const size_t total = (size_t)N * K / 4;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (act_dtype == MI355Q_BF16)
+    hipLaunchKernelGGL((w8a16_dequantize_kernel<BF16>), grid, block, 0, (hipStream_t)stream, (const uint8_t*)w,
+                       scales, (uint16_t*)out, N, K, block_n, block_k, scale_cols);
+  else
+    hipLaunchKernelGGL((w8a16_dequantize_kernel<FP16>), grid, block, 0, (hipStream_t)stream, (const uint8_t*)w,
+                       scales, (uint16_t*)out, N, K, block_n, block_k, scale_cols);
+  return check_launch("w8a16_dequantize_kernel");
+}

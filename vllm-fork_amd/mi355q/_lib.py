@@ -40,6 +40,8 @@ _SIGS = {
     "mi355q_w4a16_gemm_silu_mul": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int,
                                            c_int, c_int, c_int, c_vp, c_sz, c_int, c_vp]),
     "mi355q_w4a16_dequantize": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_w8a16_gemm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_w8a16_dequantize": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_linear_skinny": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_rms_norm": (c_int, [c_vp, c_vp, c_i64, c_vp, c_f32, c_int, c_int, c_int, c_vp]),
     "mi355q_fused_add_rms_norm": (c_int, [c_vp, c_i64, c_vp, c_vp, c_f32, c_int, c_int, c_int, c_vp]),

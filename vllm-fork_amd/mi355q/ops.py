@@ -193,6 +193,61 @@ def awq_dequantize(qweight: PackedW4, scales, zeros, split_k_iters: int, thx: in
     return w4a16_dequantize(qweight)
 
 
+# ---------------------------------------------------------------------------
+# fp8 weight-only
+# ---------------------------------------------------------------------------
+def _w8_blocks(weight: torch.Tensor, scales: torch.Tensor, block: tuple[int, int] | None):
+    N, K = weight.shape
+    if weight.element_size() != 1:
+        raise RuntimeError("fp8 weight must be a 1-byte tensor [N, K]")
+    if scales.dtype != torch.float32 or not scales.is_contiguous():
+        raise RuntimeError("fp8 weight scales must be a contiguous fp32 tensor")
+    if block is None:
+        if scales.numel() != N:
+            raise RuntimeError(f"per-channel scales must have {N} elements, got {scales.numel()}")
+        return 1, K
+    bn, bk = block
+    if tuple(scales.shape) != ((N + bn - 1) // bn, (K + bk - 1) // bk):
+        raise RuntimeError(f"block scales shape {tuple(scales.shape)} != "
+                           f"({(N + bn - 1) // bn}, {(K + bk - 1) // bk}) for blocks {block}")
+    return bn, bk
+
+
+def w8a16_dequantize(weight: torch.Tensor, scales: torch.Tensor, block: tuple[int, int] | None,
+                     dtype: torch.dtype) -> torch.Tensor:
+    """[N, K] 16-bit weight = round(fp8 * scale) (the tensor the reference's fallback builds,
+    vllm/model_executor/layers/quantization/fp8.py:433-454)."""
+    _need_cuda(weight, scales)
+    bn, bk = _w8_blocks(weight, scales, block)
+    N, K = weight.shape
+    out = torch.empty((N, K), dtype=dtype, device=weight.device)
+    check(_lib.lib().mi355q_w8a16_dequantize(weight.data_ptr(), scales.data_ptr(), out.data_ptr(), N, K, bn, bk,
+                                             _DT[dtype], _stream()))
+    return out
+
+
+def w8a16_gemm(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, block: tuple[int, int] | None = None,
+               bias: torch.Tensor | None = None) -> torch.Tensor:
+    """x[..., K] @ (fp8 weight[N, K] * scales)^T (+ bias) with 16-bit activations.  `scales` is
+    fp32 [N] (per output channel) or, with block=(block_n, block_k), [ceil(N/bn), ceil(K/bk)]."""
+    _need_cuda(x, weight, scales)
+    bn, bk = _w8_blocks(weight, scales, block)
+    N, K = weight.shape
+    if x.shape[-1] != K:
+        raise RuntimeError(f"input feature size {x.shape[-1]} != {K}")
+    x2 = x.reshape(-1, K)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if M > DEQUANT_MATMUL_MIN_TOKENS and not torch.cuda.is_current_stream_capturing():
+        out = torch.nn.functional.linear(x2, w8a16_dequantize(weight, scales, block, x.dtype), bias)
+        return out.reshape(x.shape[:-1] + (N,))
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(_lib.lib().mi355q_w8a16_gemm(x2.data_ptr(), x2.stride(0), weight.data_ptr(), scales.data_ptr(), _ptr(bias),
+                                       out.data_ptr(), M, N, K, bn, bk, _dt(x), _stream()))
+    return out.reshape(x.shape[:-1] + (N,))
+
+
 def linear_skinny(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
     """x[..., K] @ weight[N, K]^T (+ bias) for small token counts.  Stands in for
     ops.wvSplitK / ops.LLMM1 (vllm/_custom_ops.py:2161-2213) as used by

@@ -7,6 +7,7 @@ linear kernels, attention backend); without vLLM the package's own registries (s
 same semantics) are used, which is what the tests and the bundled Llama runner do.
 """
 from .awq import AutoAWQConfig, AutoAWQLinearMethod
+from .fp8 import Fp8Config, Fp8LinearMethod
 from .gptq import AutoGPTQConfig, AutoGPTQLinearMethod
 from .mp_kernel import (MI355XW4A16LinearKernel, MPLinearKernel, MPLinearLayerConfig, choose_mp_linear_kernel,
                         register_linear_kernel)

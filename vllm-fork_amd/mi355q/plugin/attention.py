@@ -219,7 +219,10 @@ class Attention(torch.nn.Module):
         self.kv_cache_dtype = cache_dtype
         self.layer_name = prefix
         set_default_quant_scales(self, register_buffer=True)
-        self.quant_method = BaseKVCacheMethod(quant_config) if is_quantized_kv_cache(cache_dtype) else None
+        method = quant_config.get_quant_method(self, prefix) if quant_config is not None else None
+        if not isinstance(method, BaseKVCacheMethod):
+            method = BaseKVCacheMethod(quant_config) if is_quantized_kv_cache(cache_dtype) else None
+        self.quant_method = method
         if self.quant_method is not None:
             self.quant_method.create_weights(self)
         self.impl = Mi355AttentionImpl(num_heads, head_size, scale, self.num_kv_heads, alibi_slopes, None, cache_dtype)

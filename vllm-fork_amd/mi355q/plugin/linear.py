@@ -16,7 +16,8 @@ from torch import nn
 from .. import ops
 from .parallel import (divide, get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
                        tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce)
-from .parameter import BasevLLMParameter, ModelWeightParameter, PerTensorScaleParameter
+from .parameter import (BasevLLMParameter, BlockQuantScaleParameter, ModelWeightParameter,
+                        PerTensorScaleParameter, adjust_block_scale_shard)
 from .registry import QuantizationConfig, QuantizeMethodBase
 
 
@@ -140,16 +141,21 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
             off = 0
             for i, n in enumerate(self.output_sizes):
                 size, start = n, off
-                if param.packed_dim is not None and param.packed_dim == param.output_dim:
+                if isinstance(param, BlockQuantScaleParameter):
+                    size, start = adjust_block_scale_shard(getattr(self, "weight_block_size", None), n, off)
+                elif param.packed_dim is not None and param.packed_dim == param.output_dim:
                     size, start = param.adjust_shard_indexes_for_packing(n, off)
                 self.weight_loader(param, loaded_weight.narrow(param.output_dim, start, size), i)
                 off += n
             return
         if not 0 <= loaded_shard_id < len(self.output_sizes):
             raise ValueError(f"shard id {loaded_shard_id} out of range for {len(self.output_sizes)} matrices")
+        offset = sum(self.output_sizes[:loaded_shard_id]) // self.tp_size
+        size = self.output_sizes[loaded_shard_id] // self.tp_size
+        if isinstance(param, BlockQuantScaleParameter):
+            size, offset = adjust_block_scale_shard(getattr(self, "weight_block_size", None), size, offset)
         param.load_merged_column_weight(loaded_weight=loaded_weight, shard_id=loaded_shard_id,
-                                        shard_offset=sum(self.output_sizes[:loaded_shard_id]) // self.tp_size,
-                                        shard_size=self.output_sizes[loaded_shard_id] // self.tp_size)
+                                        shard_offset=offset, shard_size=size)
 
     weight_loader_v2 = weight_loader
 
@@ -193,7 +199,9 @@ class QKVParallelLinear(ColumnParallelLinear):
                            ("k", self.total_num_kv_heads * self.head_size),
                            ("v", self.total_num_kv_heads * self.head_size)):
                 size, start = n, off
-                if param.packed_dim is not None and param.packed_dim == param.output_dim:
+                if isinstance(param, BlockQuantScaleParameter):
+                    size, start = adjust_block_scale_shard(getattr(self, "weight_block_size", None), n, off)
+                elif param.packed_dim is not None and param.packed_dim == param.output_dim:
                     size, start = param.adjust_shard_indexes_for_packing(n, off)
                 self.weight_loader(param, loaded_weight.narrow(param.output_dim, start, size), sid)
                 off += n
@@ -201,6 +209,8 @@ class QKVParallelLinear(ColumnParallelLinear):
         if loaded_shard_id not in ("q", "k", "v"):
             raise ValueError(f"Shard id for QKVParallelLinear should be 'q', 'k', or 'v', got {loaded_shard_id}.")
         offset, size = self._shard(loaded_shard_id)
+        if isinstance(param, BlockQuantScaleParameter):
+            size, offset = adjust_block_scale_shard(getattr(self, "weight_block_size", None), size, offset)
         param.load_qkv_weight(loaded_weight=loaded_weight, num_heads=self.num_kv_head_replicas,
                               shard_id=loaded_shard_id, shard_offset=offset, shard_size=size)
 

@@ -118,6 +118,19 @@ class PackedvLLMParameter(ModelWeightParameter):
     _needs = ("input_dim", "output_dim", "packed_dim", "packed_factor")
 
 
+class BlockQuantScaleParameter(ModelWeightParameter):
+    """One scale per (block_n x block_k) tile of the weight (parameter.py:397-403).  The linear
+    layers convert shard offsets and sizes from channels to tiles before calling the loaders."""
+
+
+def adjust_block_scale_shard(weight_block_size, shard_size: int, shard_offset: int) -> tuple[int, int]:
+    """Channels -> scale tiles along the output dimension, rounding up (linear.py:85-96)."""
+    if weight_block_size is None:
+        raise ValueError("a block-quantised layer must set weight_block_size")
+    bn = weight_block_size[0]
+    return (shard_size + bn - 1) // bn, (shard_offset + bn - 1) // bn
+
+
 class PerTensorScaleParameter(BasevLLMParameter):
     """One scale per logical matrix of a fused layer (parameter.py:260-310): shard ids
     'q'/'k'/'v' or 0/1/... select the slot."""
