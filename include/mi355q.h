@@ -158,6 +158,43 @@ int mi355q_w4a16_dequantize(const void* packed, const void* scales, const void* 
                             int K, int N, int G, int tile, int act_dtype, mi355q_stream_t stream);
 
 /* ------------------------------------------------------------------ */
+/* Mixture of experts, 4-bit experts (MoE WNA16)                       */
+/* ------------------------------------------------------------------ */
+/*
+ * Router: probs = softmax(gating_output[t, :]) in fp32, the topk largest (ties: lowest expert
+ * index) with their probabilities, optionally renormalised to sum to 1.  Replaces ops.topk_softmax
+ * (vllm/_custom_ops.py:2385; csrc/libtorch_stable/moe/topk_softmax_kernels.cu).
+ *   topk_weights fp32 [T, topk], topk_ids int32 [T, topk], gating_output [T, E] in `dtype`.
+ */
+int mi355q_topk_softmax(float* topk_weights, int32_t* topk_ids, const void* gating_output,
+                        int num_tokens, int num_experts, int topk, int renormalize, int dtype,
+                        mi355q_stream_t stream);
+/*
+ * Expert GEMM for decode: output row r ("slot" = one (token, selected expert) pair) is
+ *   c[r, :] = x[r / x_row_div, :] * dequant(W[expert_ids[r]])      (fuse_silu_mul = 0)
+ *   c[r, :] = (silu(x[r, :K]) * x[r, K:2K]) * dequant(W[expert_ids[r]])   (fuse_silu_mul = 1)
+ * with every expert's weight repacked by mi355q_w4a16_repack (same tile width) and stored
+ * back to back: packed [E][K*N/2 bytes], scales [E][K/G][N], zc [E][K/G][N] or NULL.
+ * expert_ids[r] < 0 (expert held by another rank) zero-fills the row.  No token sorting /
+ * padding pass is needed (the reference runs moe_align_block_size first).  Replaces
+ * ops.moe_wna16_gemm (vllm/_custom_ops.py:2307-2342; csrc/moe/moe_wna16.cu:16-350) and the Triton
+ * fused_moe_kernel_gptq_awq (fused_moe.py:64-296) for small token counts; x_row_div = topk for
+ * the first GEMM (w13: every slot of a token reads the token's row), 1 for the second (w2).
+ */
+int mi355q_moe_w4a16_gemm(const void* x, int ldx, int x_row_div, const void* packed,
+                          const void* scales, const void* zc, const int32_t* expert_ids, void* c,
+                          int slots, int num_experts, int N, int K, int G, int tile, int act_dtype,
+                          int fuse_silu_mul, mi355q_stream_t stream);
+/*
+ * out[t, :] = round(sum_j topk_weights[t, j] * expert_out[t * topk + j, :]), fp32 sum in
+ * slot order (topk_weights NULL: plain sum).  Replaces ops.moe_sum (vllm/_custom_ops.py:2228;
+ * moe_align_sum_kernels.cu) together with the routed-weight multiply of the expert GEMM
+ * epilogue (fused_moe.py MUL_ROUTED_WEIGHT).
+ */
+int mi355q_moe_sum(void* out, const void* expert_out, const float* topk_weights, int num_tokens,
+                   int topk, int hidden, int dtype, mi355q_stream_t stream);
+
+/* ------------------------------------------------------------------ */
 /* fp8 weight-only (W8A16) linear                                      */
 /* ------------------------------------------------------------------ */
 /*

@@ -493,8 +493,89 @@ def gen_w8a16():
     save("w8a16", names=np.array(names), restated=np.array([1]), **out)
 
 
+def gen_moe():
+    """Inputs of tests/kernels/moe/test_moe.py:590-652 (test_fused_moe_wn16: a, w/10, score, weights
+    quantised by quantize_weights and packed two nibbles per byte, even index low) and the
+    expected output of tests.kernels.utils.torch_moe on the dequantised reference weights
+    (:696), computed here on CPU."""
+    def restated_torch_moe(a, w1, w2, score, topk):   # tests/kernels/utils.py:912-1078, bf16 branch
+        score = torch.softmax(score, dim=-1, dtype=torch.float32)
+        topk_weight, topk_ids = torch.topk(score, topk)
+        M, K = a.shape
+        a = a.view(M, -1, K).repeat(1, topk, 1).reshape(-1, K)
+        out = torch.zeros(M * topk, w2.shape[1], dtype=a.dtype)
+        ids = topk_ids.view(-1)
+        for i in range(w1.shape[0]):
+            mask = ids == i
+            if mask.sum():
+                tmp1 = a[mask] @ w1[i].transpose(0, 1)
+                d = tmp1.shape[-1] // 2
+                tmp2 = torch.nn.functional.silu(tmp1[..., :d]) * tmp1[..., d:]
+                out[mask] = tmp2 @ w2[i].transpose(0, 1)
+        return (out.view(M, -1, w2.shape[1]).to(torch.float32) * topk_weight.view(M, -1, 1)).sum(dim=1).to(out.dtype)
+
+    ref_moe, ctx = None, None
+    try:
+        ref_moe = imp("tests.kernels.utils").torch_moe
+        cfg = imp("vllm.config")
+        ctx = lambda: cfg.set_current_vllm_config(cfg.VllmConfig())  # noqa: E731
+        with ctx():
+            ref_moe(torch.zeros(1, 32, dtype=torch.bfloat16), torch.zeros(2, 64, 32, dtype=torch.bfloat16),
+                    torch.zeros(2, 32, 32, dtype=torch.bfloat16), torch.zeros(1, 2, dtype=torch.bfloat16), 1)
+        restated = 0
+    except Exception as exc:
+        print("reference torch_moe not runnable here (%s: %s); using its restatement" % (type(exc).__name__, str(exc)[:120]))
+        ref_moe, restated = None, 1
+
+    def torch_moe(a, w1, w2, score, topk):
+        if ref_moe is None:
+            return restated_torch_moe(a, w1, w2, score, topk)
+        with ctx():
+            got = ref_moe(a, w1, w2, score, topk)
+        assert torch.equal(got, restated_torch_moe(a, w1, w2, score, topk)), "restatement drifted from the reference"
+        return got
+
+    out, names = {}, []
+    dtype = torch.bfloat16
+    for tag, m, n, k, e, topk, G, has_zp in [("m1_sym", 1, 128, 256, 8, 2, 64, False), ("m3_zp", 3, 128, 256, 8, 2, 128, True),
+                                             ("m33_zp", 33, 64, 128, 4, 2, 64, True), ("m2_top6", 2, 64, 128, 8, 6, 32, False)]:
+        torch.manual_seed(7)
+        a = torch.randn((m, k), dtype=dtype) / 10
+        w1 = torch.randn((e, 2 * n, k), dtype=dtype) / 10
+        w2 = torch.randn((e, k, n), dtype=dtype) / 10
+        score = torch.randn((m, e), dtype=dtype)
+        qt = st.uint4 if has_zp else st.uint4b8
+        packs = {}
+        for which, w in (("w1", w1), ("w2", w2)):
+            ref = torch.empty_like(w)
+            qws, scs, zps = [], [], []
+            for i in range(e):
+                weight, qweight, scales, qzeros = qu.quantize_weights(w[i].T, qt, G, has_zp, False)
+                ref[i] = weight.T
+                qweight = qweight.T.contiguous().to(torch.uint8)
+                qws.append(qweight[:, 1::2] * 16 + qweight[:, ::2])
+                scs.append(scales.T.contiguous())
+                if has_zp:
+                    qz = qzeros.T.contiguous().to(torch.uint8)
+                    zps.append(qz[1::2, :] * 16 + qz[::2, :])
+            packs[which] = (ref, torch.stack(qws), torch.stack(scs), torch.stack(zps) if has_zp else None)
+        expect = torch_moe(a, packs["w1"][0], packs["w2"][0], score, topk)
+        names.append(tag)
+        out[tag + "_meta"] = np.array([m, n, k, e, topk, G, int(has_zp)])
+        out[tag + "_a"] = bits16(a)
+        out[tag + "_score"] = bits16(score)
+        for which in ("w1", "w2"):
+            ref, qw, sc, zp = packs[which]
+            out[f"{tag}_{which}_q"] = qw.numpy()
+            out[f"{tag}_{which}_s"] = bits16(sc)
+            if zp is not None:
+                out[f"{tag}_{which}_z"] = zp.numpy()
+        out[tag + "_ref"] = bits16(expect)
+    save("moe", names=np.array(names), restated=np.array([restated]), **out)
+
+
 GENERATORS = {"pack": gen_pack, "quantize": gen_quantize, "w4a16": gen_w4a16, "awq": gen_awq, "rmsnorm": gen_rmsnorm,
-              "rope": gen_rope, "paged_attn": gen_paged_attn, "sampler": gen_sampler, "w8a16": gen_w8a16}
+              "rope": gen_rope, "paged_attn": gen_paged_attn, "sampler": gen_sampler, "w8a16": gen_w8a16, "moe": gen_moe}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or GENERATORS):

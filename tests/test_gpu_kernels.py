@@ -643,3 +643,87 @@ def test_w8a16_bad_arguments():
         ops.w8a16_gemm(x, w, torch.ones((1, 2), device=DEV), (64, 32))
     with pytest.raises(RuntimeError, match="multiple of 16"):
         ops.w8a16_gemm(x, w, torch.ones((1, 16), device=DEV), (64, 8))
+
+
+# ---------------------------------------------------------------------------
+# mixture of experts
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("T,E,topk,renorm,dt", [(1, 8, 2, True, torch.bfloat16), (5, 8, 2, False, torch.float32),
+                                                (3, 64, 6, True, torch.float16), (2, 160, 8, False, torch.float32),
+                                                (4, 4, 4, True, torch.bfloat16)])
+def test_topk_softmax(T, E, topk, renorm, dt):
+    torch.manual_seed(E + topk)
+    g = torch.randn((T, E), dtype=torch.float32).to(dt)
+    g[0, 1] = g[0, 0]                                   # a tie: the lower expert index wins
+    w = torch.empty((T, topk), dtype=torch.float32, device=DEV)
+    ids = torch.empty((T, topk), dtype=torch.int32, device=DEV)
+    ops.topk_softmax(w, ids, None, g.to(DEV), renorm)
+    p = torch.softmax(g.float(), dim=-1)
+    order = torch.argsort(-p, dim=-1, stable=True)[:, :topk]
+    ref_w = p.gather(1, order)
+    if renorm:
+        ref_w = ref_w / ref_w.sum(-1, keepdim=True)
+    assert torch.equal(ids.cpu().long(), order)
+    torch.testing.assert_close(w.cpu(), ref_w, rtol=2e-6, atol=1e-7)
+
+
+def _moe_case(g, tag):
+    m, n, k, e, topk, G, has_zp = [int(v) for v in g[tag + "_meta"]]
+    w1 = (g[tag + "_w1_q"], g[tag + "_w1_s"], g[tag + "_w1_z"] if has_zp else None)
+    w2 = (g[tag + "_w2_q"], g[tag + "_w2_s"], g[tag + "_w2_z"] if has_zp else None)
+    dev = [ops.moe_w4a16_repack(torch.from_numpy(w[0]).to(DEV), to_dev(w[1]),
+                                None if w[2] is None else torch.from_numpy(w[2]).to(DEV), G) for w in (w1, w2)]
+    return (m, n, k, e, topk, G, has_zp), w1, w2, dev
+
+
+def test_moe_golden_and_oracle(golden, monkeypatch):
+    """The expert path against the reference's expected outputs (tests/kernels/moe/test_moe.py:698,
+    atol 2e-2) and, tightly, against the oracle restatement with fp32 weights; both the per-slot
+    kernel route and the grouped dense route for many tokens."""
+    import moe_ref
+    from mi355q.plugin import fused_experts, fused_topk, moe as moe_mod
+    g = golden("moe")
+    for tag in g["names"]:
+        tag = str(tag)
+        (m, n, k, e, topk, G, has_zp), w1, w2, (d13, d2) = _moe_case(g, tag)
+        a = to_dev(g[tag + "_a"])
+        tw, ids = fused_topk(to_dev(g[tag + "_score"]), topk, False)
+        rw, rids = moe_ref.route(g[tag + "_score"], topk)
+        assert np.array_equal(ids.cpu().numpy(), rids), tag
+        np.testing.assert_allclose(tw.cpu().numpy(), rw, rtol=1e-5)
+        ref = f32(g[tag + "_ref"])
+        exact = f32(moe_ref.moe(g[tag + "_a"], w1, w2, rw, rids, G))
+        for limit in (1 << 30, 0):    # slot route, grouped dense route
+            monkeypatch.setattr(moe_mod, "SLOT_ROUTE_MAX", limit)
+            out = f32(to_bits(fused_experts(a, d13, d2, tw, ids)))
+            np.testing.assert_allclose(out, ref, rtol=0, atol=2e-2, err_msg=tag)
+            np.testing.assert_allclose(out, exact, rtol=1e-2, atol=2e-3, err_msg=tag)
+
+
+def test_moe_expert_map_and_sum():
+    """Slots whose expert lives on another rank contribute nothing; moe_sum without weights is a
+    plain fp32 sum."""
+    import moe_ref
+    from mi355q.plugin import fused_experts
+    rng = np.random.default_rng(12)
+    E, H, I, G, T, topk = 4, 128, 64, 32, 3, 2
+    w1 = (rng.integers(0, 256, size=(E, 2 * I, H // 2), dtype=np.uint8),
+          orc.f32_to_h16((0.02 * rng.random((E, 2 * I, H // G)) + 0.005).astype(np.float32)), None)
+    w2 = (rng.integers(0, 256, size=(E, H, I // 2), dtype=np.uint8),
+          orc.f32_to_h16((0.02 * rng.random((E, H, I // G)) + 0.005).astype(np.float32)), None)
+    emap = np.array([-1, 0, -1, 1], dtype=np.int32)           # this rank holds global experts 1 and 3
+    local = [1, 3]
+    d13 = ops.moe_w4a16_repack(torch.from_numpy(w1[0][local]).to(DEV), to_dev(w1[1][local]), None, G)
+    d2 = ops.moe_w4a16_repack(torch.from_numpy(w2[0][local]).to(DEV), to_dev(w2[1][local]), None, G)
+    a = orc.f32_to_h16(rng.standard_normal((T, H)).astype(np.float32))
+    ids = np.array([[0, 1], [3, 2], [1, 3]], dtype=np.int32)
+    tw = rng.random((T, topk)).astype(np.float32)
+    out = fused_experts(to_dev(a), d13, d2, torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV),
+                        torch.from_numpy(emap).to(DEV))
+    ref = moe_ref.moe(a, (w1[0][local], w1[1][local], None), (w2[0][local], w2[1][local], None), tw, ids, G,
+                      expert_map=emap)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=2e-3)
+    y = torch.randn((T, topk, H), device=DEV).to(torch.bfloat16)
+    s = torch.empty((T, H), dtype=torch.bfloat16, device=DEV)
+    ops.moe_sum(y, s)
+    assert torch.equal(s, y.float().sum(1).to(torch.bfloat16))

@@ -322,3 +322,50 @@ def test_fp8_online_quantisation_of_16bit_checkpoint():
     got = lin(x.to(DEV)).float().cpu()
     # e4m3 keeps 3 mantissa bits: relative weight error <= 2^-4, averaged down over K terms
     assert float((got - ref).abs().max()) < 0.06 * float(ref.abs().max())
+
+
+def test_fused_moe_layer_awq_checkpoint():
+    """FusedMoE built from an AWQ MoE checkpoint config: loader conversion, repack, routing and
+    the expert GEMMs, against the oracle restatement of the reference's torch_moe."""
+    import moe_ref
+    from mi355q.plugin import FusedMoE, MoeWNA16Config
+    rng = np.random.default_rng(13)
+    E, H, I, G, T, topk = 4, 256, 128, 64, 2, 2
+    cfg = MoeWNA16Config.from_config({"quant_method": "awq", "bits": 4, "group_size": G, "zero_point": True})
+    with torch.device(DEV):
+        moe = FusedMoE(E, topk, H, I, params_dtype=torch.bfloat16, renormalize=True, quant_config=cfg,
+                       prefix="model.layers.0.block_sparse_moe.experts")
+    ck = {}
+    for e in range(E):
+        for sid, (K, N) in (("w1", (H, I)), ("w3", (H, I)), ("w2", (I, H))):
+            q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+            z = rng.integers(0, 16, size=(K // G, N), dtype=np.int32)
+            s = orc.f32_to_h16((0.02 * rng.random((K // G, N)) + 0.005).astype(np.float32))
+            ck[e, sid] = (q, z, s)
+            name = f"experts.{e}.{sid}"
+            target = ("w2" if sid == "w2" else "w13")
+            moe.weight_loader(getattr(moe, target + "_qweight"), torch.from_numpy(orc.pack_cols(q, awq_order=True)),
+                              name + ".qweight", sid, e)
+            moe.weight_loader(getattr(moe, target + "_qzeros"), torch.from_numpy(orc.pack_cols(z, awq_order=True)),
+                              name + ".qzeros", sid, e)
+            moe.weight_loader(getattr(moe, target + "_scales"), to_dev(s).cpu(), name + ".scales", sid, e)
+    moe.process_weights_after_loading()
+    x = orc.f32_to_h16(rng.standard_normal((T, H)).astype(np.float32))
+    logits = orc.f32_to_h16(rng.standard_normal((T, E)).astype(np.float32))
+    got = moe(to_dev(x), to_dev(logits))
+
+    def packed(sids):   # byte layout of the reference loader from the logical values
+        qs, zs, ss = [], [], []
+        for e in range(E):
+            q = np.concatenate([ck[e, s][0] for s in sids], axis=1)          # [K, N]
+            z = np.concatenate([ck[e, s][1] for s in sids], axis=1)          # [K/G, N]
+            sc = np.concatenate([ck[e, s][2] for s in sids], axis=1)
+            qt, zt = q.T, z.T                                                # [N, K], [N, K/G]
+            qs.append((qt[:, 1::2] * 16 + qt[:, ::2]).astype(np.uint8))
+            zs.append((zt[1::2] * 16 + zt[::2]).astype(np.uint8))
+            ss.append(np.ascontiguousarray(sc.T))
+        return np.stack(qs), np.stack(ss), np.stack(zs)
+
+    w, ids = moe_ref.route(logits, topk, renormalize=True)
+    ref = moe_ref.moe(x, packed(("w1", "w3")), packed(("w2",)), w, ids, G)
+    np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=2e-3)

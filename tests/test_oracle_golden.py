@@ -193,3 +193,20 @@ def test_w8a16_fallback_linear(golden):
         wt = torch.from_numpy(w).view(torch.float8_e4m3fn).to(torch.bfloat16) * \
             torch.from_numpy(scale).to(torch.bfloat16).unsqueeze(1)
         assert np.array_equal(deq, wt.float().numpy()), tag
+
+
+def test_moe_wna16_expert_path(golden):
+    """Restated torch_moe of the reference (tests/kernels/utils.py:912-1078) on the inputs of
+    test_fused_moe_wn16 (tests/kernels/moe/test_moe.py:590-698), tolerance of :698 (atol 2e-2)."""
+    import moe_ref
+    g = golden("moe")
+    for tag in g["names"]:
+        tag = str(tag)
+        m, n, k, e, topk, G, has_zp = [int(v) for v in g[tag + "_meta"]]
+        w1 = (g[tag + "_w1_q"], g[tag + "_w1_s"], g[tag + "_w1_z"] if has_zp else None)
+        w2 = (g[tag + "_w2_q"], g[tag + "_w2_s"], g[tag + "_w2_z"] if has_zp else None)
+        w, ids = moe_ref.route(g[tag + "_score"], topk)
+        ref = f32(g[tag + "_ref"])
+        for rw in (True, False):   # bf16-rounded weights (what torch_moe multiplies) and fp32 weights (the kernels)
+            out = f32(moe_ref.moe(g[tag + "_a"], w1, w2, w, ids, G, round_weight=rw))
+            np.testing.assert_allclose(out, ref, rtol=0, atol=2e-2, err_msg=f"{tag} round_weight={rw}")

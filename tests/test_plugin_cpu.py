@@ -395,3 +395,67 @@ def test_fp8_block_scales_shard_on_tiles(tp):
     with pytest.raises(ValueError, match="not divisible by weight quantization block_k"):
         RowParallelLinear(inter, hidden, bias=False, params_dtype=torch.bfloat16,
                           quant_config=Fp8Config(True, "dynamic", weight_block_size=[64, 128]), prefix="down")
+
+
+# ---------------------------------------------------------------------------
+# mixture of experts
+# ---------------------------------------------------------------------------
+def test_moe_config_and_loader_conversions(tp):
+    import moe_ref
+    from mi355q.plugin import FusedMoE, MoeWNA16Config
+    from mi355q.plugin.moe import convert_awq_tensor, convert_gptq_int4_qzeros
+    c = MoeWNA16Config.from_config(dict(AWQ_CFG, bits=4, group_size=64, quant_method="awq"))
+    assert c.has_zp and c.bit8_pack_factor == 2
+    assert MoeWNA16Config.override_quantization_method(dict(GPTQ_CFG), "moe_wna16") == "moe_wna16"
+    assert MoeWNA16Config.override_quantization_method(dict(GPTQ_CFG), None) is None
+    assert not MoeWNA16Config.is_moe_wna16_compatible(dict(GPTQ_CFG, desc_act=True))
+    with pytest.raises(ValueError, match="only support gptq and awq"):
+        MoeWNA16Config.from_config({"quant_method": "fp8", "bits": 4, "group_size": 64})
+    # AWQ tensors -> byte layout: value-exact against the oracle's unpackers
+    rng = np.random.default_rng(11)
+    K, N, G = 64, 32, 32
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    z = rng.integers(0, 16, size=(K // G, N), dtype=np.int32)
+    qw = convert_awq_tensor(_t(orc.pack_cols(q, awq_order=True)), "qweight").numpy()
+    qz = convert_awq_tensor(_t(orc.pack_cols(z, awq_order=True)), "qzeros").numpy()
+    assert qw.shape == (N, K // 2) and np.array_equal(moe_ref.unpack_moe_weight(qw), q)
+    assert qz.shape == (N // 2, K // G) and np.array_equal(moe_ref.unpack_moe_zeros(qz), z)
+    zg = rng.integers(0, 15, size=(K // G, N), dtype=np.int32)   # stored z - 1 < 15
+    got = convert_gptq_int4_qzeros(_t(orc.pack_cols(zg))).numpy()
+    assert np.array_equal((got & 0xF), zg[:, 0::2] + 1) and np.array_equal(got >> 4, zg[:, 1::2] + 1)
+
+    # layer shapes, group-size halving, TP sharding of the expert tensors, host repack
+    E, H, I = 4, 128, 192          # I/2 = 96 per rank: group 64 does not divide it -> 32
+    full = MoeWNA16Config.from_config(dict(GPTQ_CFG, group_size=64))
+    w1 = rng.integers(0, 16, size=(E, H, I), dtype=np.int32)     # checkpoint orientation [K, N]
+    w2 = rng.integers(0, 16, size=(E, I, H), dtype=np.int32)
+    s1 = rng.random((E, H // 64, I)).astype(np.float32)
+    for rank in range(2):
+        tp(rank, 2)
+        moe = FusedMoE(E, 2, H, I, params_dtype=torch.bfloat16, quant_config=full, prefix="mlp.experts")
+        assert moe.group_size == 32 and moe.group_size_div_factor == 2
+        assert moe.w13_qweight.shape == (E, I, H // 2) and moe.w2_qweight.shape == (E, H, I // 4)
+        assert moe.w13_scales.shape == (E, I, H // 32) and not hasattr(moe, "w13_qzeros")
+        for e in range(E):
+            for sid in ("w1", "w3"):
+                moe.weight_loader(moe.w13_qweight, _t(orc.gptq_pack(w1[e])), f"experts.{e}.{sid}.qweight", sid, e)
+                moe.weight_loader(moe.w13_scales, torch.from_numpy(s1[e]).to(torch.bfloat16),
+                                  f"experts.{e}.{sid}.scales", sid, e)
+            moe.weight_loader(moe.w2_qweight, _t(orc.gptq_pack(w2[e])), f"experts.{e}.w2.qweight", "w2", e)
+            assert moe.weight_loader(moe.w2_qweight, torch.zeros(1), f"experts.{e}.w2.g_idx", "w2", e, True) is False
+        half = I // 2
+        for e in range(E):
+            got13 = moe_ref.unpack_moe_weight(moe.w13_qweight.data[e].numpy())           # [K=H, N=2*half]
+            exp = w1[e][:, rank * half:(rank + 1) * half]
+            assert np.array_equal(got13, np.concatenate([exp, exp], axis=1))
+            got2 = moe_ref.unpack_moe_weight(moe.w2_qweight.data[e].numpy())             # [K=half, N=H]
+            assert np.array_equal(got2, w2[e][rank * half:(rank + 1) * half])
+            sc = moe.w13_scales.data[e].float().numpy()                                  # [2*half, H/32]
+            exp_s = torch.from_numpy(s1[e]).to(torch.bfloat16).float().numpy()[:, rank * half:(rank + 1) * half].T
+            assert np.array_equal(sc[:half], np.repeat(exp_s, 2, axis=1))
+        moe.process_weights_after_loading()
+        assert moe.w13_packed.E == E and moe.w13_packed.K == H and moe.w13_packed.N == 2 * half
+        w = moe.w2_packed.expert(1)
+        back = np.empty((w.K, w.N), dtype=np.int32)
+        _lib.check(_lib.lib().mi355q_w4a16_unpack_host(w.packed.data_ptr(), back.ctypes.data, w.K, w.N, w.tile))
+        assert np.array_equal(back, w2[1][rank * half:(rank + 1) * half])

@@ -245,6 +245,15 @@ struct SkinnyParams {
   int chunks;              // K / (32 * CS)
   int splits;
   int nw;                  // waves per workgroup
+  // Row tiling: blockIdx.z owns output rows [z * mrows, z * mrows + mrows).  Dense GEMMs use 16
+  // (one MFMA tile of rows).  Mixture-of-experts launches use 1: output row z is one
+  // (token, selected expert) slot, its weights are those of expert_ids[z] (negative: the row is
+  // zero-filled) and its input row is z / x_row_div.
+  int mrows;
+  int x_row_div;
+  const int* expert_ids;   // [M] or null
+  long long wp_estride;    // u32x4 units between experts
+  long long sc_estride;    // 16-bit elements between experts (scales and zc)
 };
 
 template <typename DT>
@@ -312,11 +321,26 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
   const int tiles = p.K / (32 * KT);
   const int c0 = (int)(((long long)p.chunks * sp) / p.splits);
   const int c1 = (int)(((long long)p.chunks * (sp + 1)) / p.splits);
-  const int Mt = min(16, p.M - mt * 16);
-  const int mrow = mt * 16 + min(ml, Mt - 1);
+  const int row0 = mt * p.mrows;
+  const int Mt = min(p.mrows, p.M - row0);
+  const int mrow = row0 + min(ml, Mt - 1);
 
-  const u32x4* wstrip = p.wp + (size_t)strip * tiles * 64 + lane;
-  const uint16_t* xrow = p.x + (size_t)mrow * p.ldx + 8 * kq;
+  const u32x4* wexp = p.wp;
+  const uint16_t* sc_e = p.scales;
+  const uint16_t* zc_e = p.zc;
+  if (p.expert_ids) {
+    const int expert = p.expert_ids[mt];
+    if (expert < 0) {  // slot routed to an expert this rank does not hold: the row is zero
+      if (sp == 0 && threadIdx.x < SW / 4)
+        *reinterpret_cast<u32x2*>(p.out + (size_t)row0 * p.N + strip * SW + 4 * threadIdx.x) = u32x2{0u, 0u};
+      return;
+    }
+    wexp += (size_t)expert * p.wp_estride;
+    sc_e += (size_t)expert * p.sc_estride;
+    if (zc_e) zc_e += (size_t)expert * p.sc_estride;
+  }
+  const u32x4* wstrip = wexp + (size_t)strip * tiles * 64 + lane;
+  const uint16_t* xrow = p.x + (size_t)(mrow / p.x_row_div) * p.ldx + 8 * kq;
   const int kbase = c0 * CS * 32;  // first k of this block's range
   const int krange = (c1 - c0) * CS * 32;
   const uint16_t* arow = act + (size_t)min(ml, Mt - 1) * krange + 8 * kq;
@@ -329,7 +353,7 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
 #pragma unroll
     for (int t = 0; t < CT; t++) w[slot][t] = __builtin_nontemporal_load(wstrip + (size_t)(c * CT + t) * 64);
     const int g = (c * CS * 32) / p.G;
-    sc[slot] = load_dwords<ND>(p.scales + (size_t)g * p.N + sc_off);
+    sc[slot] = load_dwords<ND>(sc_e + (size_t)g * p.N + sc_off);
   };
   auto issue_b = [&](int c, int slot) {
 #pragma unroll
@@ -358,7 +382,7 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
     const int vecs = krange >> 3;
     for (int idx = threadIdx.x; idx < Mt * vecs; idx += nthreads) {
       const int m = idx / vecs, v = idx - m * vecs;
-      const uint16_t* src = p.x + (size_t)(mt * 16 + m) * p.ldx + kbase + 8 * v;
+      const uint16_t* src = p.x + (size_t)((row0 + m) / p.x_row_div) * p.ldx + kbase + 8 * v;
       const u32x4 g = *reinterpret_cast<const u32x4*>(src);
       const u32x4 u = *reinterpret_cast<const u32x4*>(src + p.K);
       u32x4 o;
@@ -387,7 +411,7 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
 #pragma unroll
         for (int m = 0; m < 4; m++) {
           if (m < nm) {
-            const size_t off = (size_t)(mt * 16 + mb + m);
+            const size_t off = (size_t)(row0 + mb + m);
             const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + off * p.ldx + 8 * v);
             u32x4 rv = u32x4{0u, 0u, 0u, 0u};
             if (p.res_in) rv = *reinterpret_cast<const u32x4*>(p.res_in + off * p.K + 8 * v);
@@ -421,7 +445,7 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
       const int vecs = krange >> 3;
       for (int idx = threadIdx.x; idx < nm * vecs; idx += nthreads) {
         const int m = idx / vecs, v = idx - m * vecs;
-        const size_t off = (size_t)(mt * 16 + mb + m);
+        const size_t off = (size_t)(row0 + mb + m);
         const int k = kbase + 8 * v;
         const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + off * p.ldx + k);
         u32x4 rv = u32x4{0u, 0u, 0u, 0u}, wv = u32x4{0u, 0u, 0u, 0u};
@@ -459,7 +483,7 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
 
   auto consume = [&](int c, int slot, int bslot) {
     Dwords<ND> zz;
-    if constexpr (HAS_ZC) zz = load_dwords<ND>(p.zc + (size_t)((c * CS * 32) / p.G) * p.N + sc_off);
+    if constexpr (HAS_ZC) zz = load_dwords<ND>(zc_e + (size_t)((c * CS * 32) / p.G) * p.N + sc_off);
     f32x4 acc[NS], acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NS; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -523,7 +547,7 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
   constexpr int QW = SW / 4;
   const int m_l = threadIdx.x / QW, nq = threadIdx.x % QW;
   const bool active = threadIdx.x < 4 * SW && m_l < Mt;
-  const int m = mt * 16 + m_l;
+  const int m = row0 + m_l;
   const int n = strip * SW + 4 * nq;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   if (active) {
@@ -638,7 +662,7 @@ static Plan make_plan(int M, int N, int K, int G, int sw, bool lds_prologue, int
 
 template <typename DT, int SW, int PRO>
 static int launch_sw(const SkinnyParams& p, int CS, hipStream_t stream, size_t lds) {
-  dim3 grid(p.N / SW, p.splits, (p.M + 15) / 16), block(p.nw * 64);
+  dim3 grid(p.N / SW, p.splits, (p.M + p.mrows - 1) / p.mrows), block(p.nw * 64);
   const bool zc = p.zc != nullptr;
 #define MI355Q_LAUNCH(cs, z) \
   hipLaunchKernelGGL((w4a16_skinny_kernel<DT, SW, cs, z, PRO>), grid, block, lds, stream, p)
@@ -669,10 +693,16 @@ struct NormArgs {
   float eps;
 };
 
+struct MoeArgs {
+  const int* expert_ids;  // [M] expert of every output row, negative = not on this rank
+  int x_row_div;          // input row of output row r is r / x_row_div
+  int num_experts;
+};
+
 static int gemm_impl(const void* x, int ldx, const void* packed, const void* scales, const void* zc,
                      const void* bias, void* c, int M, int N, int K, int G, int sw, int act_dtype,
                      void* workspace, size_t workspace_bytes, int split_k, hipStream_t stream,
-                     int pro, const NormArgs* na) {
+                     int pro, const NormArgs* na, const MoeArgs* moe = nullptr) {
   if (int e = check_shape(K, N, G)) return e;
   if (int e = check_tile(sw, K, G)) return e;
   MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w4a16_gemm: act_dtype must be bf16 or fp16");
@@ -704,15 +734,26 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
     p.eps = na->eps;
   }
   p.M = M; p.N = N; p.K = K; p.G = G;
+  p.mrows = 16; p.x_row_div = 1; p.expert_ids = nullptr; p.wp_estride = 0; p.sc_estride = 0;
+  if (moe) {
+    MI355Q_REQUIRE(moe->expert_ids && moe->x_row_div >= 1 && moe->num_experts >= 1, "moe_w4a16_gemm: bad expert arguments");
+    MI355Q_REQUIRE(pro != PRO_ADDNORM && bias == nullptr, "moe_w4a16_gemm: no bias or norm prologue");
+    p.mrows = 1;
+    p.x_row_div = moe->x_row_div;
+    p.expert_ids = moe->expert_ids;
+    p.wp_estride = (long long)K * N / 32;   // K*N/2 bytes per expert
+    p.sc_estride = (long long)(K / G) * N;
+    split_k = 1;                            // rows of different experts never share a tile
+  }
   p.chunks = K / (32 * CS);
   const bool lds_pro = pro != PRO_NONE;
-  const Plan plan = make_plan(M, N, K, G, sw, lds_pro, split_k);
+  const Plan plan = make_plan(moe ? 1 : M, N, K, G, sw, lds_pro, split_k);
   p.splits = plan.splits;
   p.nw = plan.nw;
   size_t lds = (size_t)p.nw * (sw / 16) * 1024 + 16;
   if (lds_pro) {
     const int pb = (p.chunks + p.splits - 1) / p.splits;
-    lds += (size_t)pb * act_bytes_per_chunk(CS, M);
+    lds += (size_t)pb * act_bytes_per_chunk(CS, moe ? 1 : M);
   }
   MI355Q_REQUIRE(lds <= 160 * 1024, "w4a16_gemm: %zu bytes of LDS needed (K range per block too long)", lds);
   p.counters = nullptr;
@@ -823,4 +864,15 @@ extern "C" int mi355q_w4a16_dequantize(const void* packed, const void* scales, c
                        (const uint32_t*)packed, (const uint16_t*)scales, (const uint16_t*)zc,
                        (uint16_t*)w, K, N, G, tile);
   return check_launch("dequantize_kernel");
+}
+
+/* ---- mixture of experts ------------------------------------------------------ */
+extern "C" int mi355q_moe_w4a16_gemm(const void* x, int ldx, int x_row_div, const void* packed,
+                                     const void* scales, const void* zc, const int32_t* expert_ids,
+                                     void* c, int slots, int num_experts, int N, int K, int G,
+                                     int tile, int act_dtype, int fuse_silu_mul,
+                                     mi355q_stream_t stream) {
+  MoeArgs moe{expert_ids, x_row_div, num_experts};
+  return gemm_impl(x, ldx, packed, scales, zc, nullptr, c, slots, N, K, G, tile, act_dtype, nullptr, 0, 1,
+                   (hipStream_t)stream, fuse_silu_mul ? PRO_SILU : PRO_NONE, nullptr, &moe);
 }

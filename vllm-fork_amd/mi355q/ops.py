@@ -194,6 +194,102 @@ def awq_dequantize(qweight: PackedW4, scales, zeros, split_k_iters: int, thx: in
 
 
 # ---------------------------------------------------------------------------
+# mixture of experts (4-bit experts)
+# ---------------------------------------------------------------------------
+class PackedMoeW4:
+    """Kernel-layout 4-bit weights of all experts of one projection (output of `moe_w4a16_repack`)."""
+
+    __slots__ = ("packed", "scales", "zc", "E", "K", "N", "G", "tile")
+
+    def __init__(self, packed, scales, zc, E, K, N, G, tile):
+        self.packed, self.scales, self.zc, self.E, self.K, self.N, self.G, self.tile = packed, scales, zc, E, K, N, G, tile
+
+    def expert(self, e: int) -> PackedW4:
+        return PackedW4(self.packed[e], self.scales[e], None if self.zc is None else self.zc[e], self.K, self.N,
+                        self.G, self.tile)
+
+
+def moe_w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor | None,
+                     group_size: int) -> PackedMoeW4:
+    """MoE WNA16 checkpoint-side layout (moe_wna16.py:204-330 after its loader conversions,
+    :516-638) -> kernel layout.  qweight uint8 [E, N, K/2], two 4-bit values per byte along K with
+    the even k in the low nibble; scales [E, N, K/G]; qzeros uint8 [E, N/2, K/G] (even n low) or
+    None for symmetric uint4b8."""
+    if qweight.dtype != torch.uint8 or qweight.dim() != 3:
+        raise RuntimeError("moe qweight must be uint8 [E, N, K/2]")
+    E, N, K2 = qweight.shape
+    K = 2 * K2
+    G = K if group_size in (-1, 0) else group_size
+    if scales.shape != (E, N, K // G):
+        raise RuntimeError(f"moe scales shape {tuple(scales.shape)} != ({E}, {N}, {K // G})")
+    if qzeros is not None and (qzeros.dtype != torch.uint8 or qzeros.shape != (E, N // 2, K // G)):
+        raise RuntimeError(f"moe qzeros must be uint8 [{E}, {N // 2}, {K // G}]")
+    tile = _lib.lib().mi355q_w4a16_choose_tile(K, N, G)
+    packed = torch.empty((E, K * N // 8), dtype=torch.int32, device=qweight.device)
+    sc = torch.empty((E, K // G, N), dtype=scales.dtype, device=qweight.device)
+    zc = None if qzeros is None else torch.empty((E, K // G, N), dtype=scales.dtype, device=qweight.device)
+    for e in range(E):
+        # four bytes = eight consecutive k, least significant nibble first: the GPTQ word, transposed
+        qw = qweight[e].contiguous().view(torch.int32).t().contiguous()              # [K/8, N]
+        qz = None
+        if qzeros is not None:
+            # [K/G, N/8], sequential nibbles (reshape gives canonical strides even when K/G == 1)
+            qz = qzeros[e].t().contiguous().reshape(-1).view(K // G, N // 2).view(torch.int32)
+        w = w4a16_repack(qw, scales[e].t().contiguous(), qz, G, _lib.W_GPTQ,
+                         _lib.ZP_CONST if qz is None else _lib.ZP_NSEQ, tile)
+        packed[e].copy_(w.packed)
+        sc[e].copy_(w.scales)
+        if zc is not None:
+            zc[e].copy_(w.zc)
+    return PackedMoeW4(packed, sc, zc, E, K, N, G, tile)
+
+
+def topk_softmax(topk_weights: torch.Tensor, topk_ids: torch.Tensor, token_expert_indices: torch.Tensor | None,
+                 gating_output: torch.Tensor, renormalize: bool = False) -> None:
+    """ops.topk_softmax (vllm/_custom_ops.py:2385): fills topk_weights (fp32) and topk_ids (int32)
+    in place; token_expert_indices is accepted and left untouched."""
+    _need_cuda(topk_weights, topk_ids, gating_output)
+    T, E = gating_output.shape
+    if topk_weights.dtype != torch.float32 or topk_ids.dtype != torch.int32 or topk_weights.shape != topk_ids.shape:
+        raise RuntimeError("topk_softmax: topk_weights must be fp32 and topk_ids int32, both [tokens, topk]")
+    if not gating_output.is_contiguous() or not topk_weights.is_contiguous() or not topk_ids.is_contiguous():
+        raise RuntimeError("topk_softmax: tensors must be contiguous")
+    check(_lib.lib().mi355q_topk_softmax(topk_weights.data_ptr(), topk_ids.data_ptr(), gating_output.data_ptr(), T, E,
+                                         topk_weights.shape[1], int(renormalize), _dt(gating_output, True), _stream()))
+
+
+def moe_w4a16_gemm(x: torch.Tensor, w: PackedMoeW4, expert_ids: torch.Tensor, x_row_div: int,
+                   fuse_silu_mul: bool = False) -> torch.Tensor:
+    """Row r of the result = x[r // x_row_div] (or silu-mul of x[r]) @ dequant(expert expert_ids[r]).
+    Stands in for ops.moe_wna16_gemm (vllm/_custom_ops.py:2307-2342) at decode sizes."""
+    _need_cuda(x, w.packed, expert_ids)
+    if expert_ids.dtype != torch.int32 or not expert_ids.is_contiguous():
+        raise RuntimeError("moe_w4a16_gemm: expert_ids must be a contiguous int32 tensor")
+    slots = expert_ids.numel()
+    Kx = w.K * (2 if fuse_silu_mul else 1)
+    if x.dim() != 2 or x.shape[1] != Kx or x.stride(1) != 1 or x.shape[0] * x_row_div < slots:
+        raise RuntimeError(f"moe_w4a16_gemm: input must be [>= {-(-slots // x_row_div)}, {Kx}]")
+    out = torch.empty((slots, w.N), dtype=x.dtype, device=x.device)
+    check(_lib.lib().mi355q_moe_w4a16_gemm(x.data_ptr(), x.stride(0), x_row_div, w.packed.data_ptr(),
+                                           w.scales.data_ptr(), _ptr(w.zc), expert_ids.data_ptr(), out.data_ptr(),
+                                           slots, w.E, w.N, w.K, w.G, w.tile, _dt(x), int(fuse_silu_mul), _stream()))
+    return out
+
+
+def moe_sum(input: torch.Tensor, output: torch.Tensor, topk_weights: torch.Tensor | None = None) -> None:
+    """ops.moe_sum(input [T, topk, H], output [T, H]) (vllm/_custom_ops.py:2228); with
+    topk_weights (fp32 [T, topk]) the rows are weighted in fp32 before the sum."""
+    _need_cuda(input, output)
+    T, topk, H = input.shape
+    if not input.is_contiguous() or not output.is_contiguous():
+        raise RuntimeError("moe_sum: tensors must be contiguous")
+    if topk_weights is not None and (topk_weights.dtype != torch.float32 or not topk_weights.is_contiguous()):
+        raise RuntimeError("moe_sum: topk_weights must be contiguous fp32")
+    check(_lib.lib().mi355q_moe_sum(output.data_ptr(), input.data_ptr(), _ptr(topk_weights), T, topk, H, _dt(input),
+                                    _stream()))
+
+
+# ---------------------------------------------------------------------------
 # fp8 weight-only
 # ---------------------------------------------------------------------------
 def _w8_blocks(weight: torch.Tensor, scales: torch.Tensor, block: tuple[int, int] | None):
