@@ -64,6 +64,13 @@ int mi355q_version(void);
  * strip.  The same value must be passed to the repack and to every GEMM.
  */
 int mi355q_w4a16_choose_tile(int K, int N, int G);
+/*
+ * Strip width for layers that serve decode: any of 16, 32, 64, 112 -- chosen so that the layer
+ * gives about one workgroup per CU (N = 28672 -> 112 channels x 256 strips).  Falls back to
+ * mi355q_w4a16_choose_tile when the group size is not a multiple of 128 or the layer is too
+ * narrow to occupy the chip without splitting K across workgroups.
+ */
+int mi355q_w4a16_choose_strip(int K, int N, int G);
 
 /*
  * Load-time repack of a 4-bit checkpoint tensor into the kernel's tiled layout

@@ -49,29 +49,54 @@ __host__ __device__ static inline uint32_t src_nibble(const int32_t* qw, int lay
 
 __host__ __device__ static inline int nibble_shift(int j) { return ((j & 1) << 4) + ((j >> 1) << 2); }
 
+// Strip widths that are not 16, 32 or 64 (NS = sw / 16 not a divisor of 4) use the same rule
+// written per 128-input-channel chunk: a chunk of a strip is NS consecutive 1 KiB planes and
+// dword e = ks * NS + sub of a lane's 4 NS dwords sits in plane e / 4 at position e % 4.  For
+// NS = 1, 2, 4 and K % 128 == 0 both rules give the same bytes.
+__host__ __device__ static inline bool chunk_rule(int ns) { return 4 % ns != 0; }
+
 // index of the packed dword holding (k, n) and the bit offset of its nibble
 __host__ __device__ static inline void packed_pos(int K, int sw, int k, int n, size_t* dword,
                                                   int* shift) {
-  const int ns = sw >> 4, kt = 4 / ns, qw = sw >> 2;
+  const int ns = sw >> 4, qw = sw >> 2;
   const int strip = n / sw, nl = n % sw;
   const int q = nl / qw, sub = (nl % qw) >> 2, r = nl & 3;
-  const int kstep = k >> 5, tile = kstep / kt, ks = kstep % kt;
+  const int kstep = k >> 5;
   const int lane = (((k >> 3) & 3) << 4) | (q << 2) | r;
-  *dword = (((size_t)strip * (K / (32 * kt)) + tile) * 64 + lane) * 4 + ks * ns + sub;
+  if (chunk_rule(ns)) {
+    const int c = kstep >> 2, e = (kstep & 3) * ns + sub;
+    *dword = ((((size_t)strip * (K >> 7) + c) * ns + (e >> 2)) * 64 + lane) * 4 + (e & 3);
+  } else {
+    const int kt = 4 / ns, tile = kstep / kt, ks = kstep % kt;
+    *dword = (((size_t)strip * (K / (32 * kt)) + tile) * 64 + lane) * 4 + ks * ns + sub;
+  }
   *shift = nibble_shift(k & 7);
 }
 
 // (k0, n) of packed dword d: its nibbles are k0 .. k0 + 7 of channel n
 __host__ __device__ static inline void dword_pos(int K, int sw, size_t d, int* k0, int* n) {
-  const int ns = sw >> 4, kt = 4 / ns;
+  const int ns = sw >> 4;
   const int i = (int)(d & 3), lane = (int)((d >> 2) & 63);
-  const size_t tile_id = d >> 8;
-  const int tiles = K / (32 * kt);
-  const int tile = (int)(tile_id % tiles), strip = (int)(tile_id / tiles);
-  const int sub = i % ns, ks = i / ns;
+  const size_t tile_id = d >> 8;   // 1 KiB plane index
   const int rho = lane & 15, kq = lane >> 4;
+  int strip, sub, kstep;
+  if (chunk_rule(ns)) {
+    const int chunks = K >> 7;
+    const int plane = (int)(tile_id % ns);
+    const size_t cid = tile_id / ns;
+    const int c = (int)(cid % chunks), e = plane * 4 + i;
+    strip = (int)(cid / chunks);
+    sub = e % ns;
+    kstep = 4 * c + e / ns;
+  } else {
+    const int kt = 4 / ns, tiles = K / (32 * kt);
+    const int tile = (int)(tile_id % tiles);
+    strip = (int)(tile_id / tiles);
+    sub = i % ns;
+    kstep = kt * tile + i / ns;
+  }
   *n = sw * strip + (sw >> 2) * (rho >> 2) + 4 * sub + (rho & 3);
-  *k0 = 32 * (kt * tile + ks) + 8 * kq;
+  *k0 = 32 * kstep + 8 * kq;
 }
 
 __host__ __device__ static inline uint32_t repack_dword(const int32_t* qw, int layout, int K, int N,
@@ -127,13 +152,18 @@ static int check_shape(int K, int N, int& G) {
 
 // a tile must not straddle a scale group: 32 * KT input channels per tile
 static bool tile_ok(int sw, int K, int G) {
-  if (sw != 64 && sw != 32 && sw != 16) return false;
-  const int kt = 4 / (sw >> 4);
+  if (sw < 16 || sw > 128 || sw % 16) return false;
+  const int ns = sw >> 4;
+  if (chunk_rule(ns)) return K % 128 == 0 && G % 128 == 0;
+  const int kt = 4 / ns;
   return chunk_steps(G) % kt == 0 && K % (32 * kt) == 0;
 }
+// strip widths the split-K capable kernel (w4a16_skinny_kernel) is built for
+static bool legacy_tile(int sw) { return sw == 64 || sw == 32 || sw == 16; }
 
-static int check_tile(int sw, int K, int G) {
+static int check_tile(int sw, int K, int G, int N = 0) {
   MI355Q_REQUIRE(tile_ok(sw, K, G), "w4a16: tile width %d is not usable with K=%d, group size %d", sw, K, G);
+  MI355Q_REQUIRE(N % sw == 0, "w4a16: N=%d is not a multiple of the tile width %d", N, sw);
   return 0;
 }
 
@@ -168,7 +198,7 @@ extern "C" int mi355q_w4a16_repack(const int32_t* qweight, const int32_t* qzeros
                                    void* zc, int K, int N, int G, int tile, int src_layout,
                                    int zp_mode, int act_dtype, mi355q_stream_t stream) {
   if (int e = check_shape(K, N, G)) return e;
-  if (int e = check_tile(tile, K, G)) return e;
+  if (int e = check_tile(tile, K, G, N)) return e;
   if (int e = check_enums(src_layout, zp_mode, act_dtype, qzeros, zc)) return e;
   MI355Q_REQUIRE(qweight && packed, "w4a16_repack: null pointer");
   const size_t nd = (size_t)K * N / 8;
@@ -190,7 +220,7 @@ extern "C" int mi355q_w4a16_repack_host(const int32_t* qweight, const int32_t* q
                                         void* packed, void* zc, int K, int N, int G, int tile,
                                         int src_layout, int zp_mode, int act_dtype) {
   if (int e = check_shape(K, N, G)) return e;
-  if (int e = check_tile(tile, K, G)) return e;
+  if (int e = check_tile(tile, K, G, N)) return e;
   if (int e = check_enums(src_layout, zp_mode, act_dtype, qzeros, zc)) return e;
   MI355Q_REQUIRE(qweight && packed, "w4a16_repack_host: null pointer");
   const size_t nd = (size_t)K * N / 8;
@@ -207,7 +237,7 @@ extern "C" int mi355q_w4a16_repack_host(const int32_t* qweight, const int32_t* q
 extern "C" int mi355q_w4a16_unpack_host(const void* packed, int32_t* q, int K, int N, int tile) {
   int G = K;
   if (int e = check_shape(K, N, G)) return e;
-  MI355Q_REQUIRE(tile == 64 || tile == 32 || tile == 16, "w4a16_unpack_host: bad tile width %d", tile);
+  MI355Q_REQUIRE(tile_ok(tile, K, G) && N % tile == 0, "w4a16_unpack_host: bad tile width %d", tile);
   const uint32_t* p = (const uint32_t*)packed;
   for (int k = 0; k < K; k++)
     for (int n = 0; n < N; n++) {
@@ -620,6 +650,421 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
   }
 }
 
+// ---------------------------------------------------------------------------
+// Burst kernel: the decode-time GEMV for scale groups that are multiples of 128.
+//
+// One workgroup per strip of SW = 16 NS output channels, strips sized so that a layer gives
+// about one workgroup per CU (e.g. 112 channels for N = 28672 on 256 CUs).  A CU ingests
+// HBM data at ~10 B/cycle however it is asked, so the only lever is to have every CU asking
+// all the time: each wave requests its first CPW chunks (NS KiB each; for most layers that is
+// everything it will ever consume) at kernel entry, before anything else can stall it,
+// consumes them in arrival order and refills a slot the moment it is consumed.  What the prologue needs (the activation row, its residual, the norm
+// weight, the strip's scales) is requested BEFORE the weights, because vector loads return
+// in issue order; its arithmetic then overlaps the weight stream.  Scales (and zero points)
+// of the whole strip are staged in LDS once.  Rows are processed rows_pp at a time (grid z).
+// ---------------------------------------------------------------------------
+struct BurstParams {
+  const uint16_t* x;
+  int ldx;
+  const u32x4* wp;
+  const uint16_t* scales;
+  const uint16_t* zc;
+  const uint16_t* bias;
+  uint16_t* out;
+  const uint16_t* res_in;
+  uint16_t* res_out;
+  const uint16_t* norm_w;
+  float eps;
+  int M, N, K;
+  int chunks;   // K / 128
+  int gchunks;  // chunks per scale group (G / 128)
+  int rows_pp;  // activation rows per pass
+  int nw;       // waves per workgroup; chunks == nw * CPW * bursts
+  int bursts;
+  unsigned long long* stamps;  // diagnostics: 4 x 100 MHz timestamps per workgroup, or null
+};
+
+static unsigned long long* g_burst_stamps = nullptr;
+
+constexpr int BURST_XV = 2;  // 16-byte activation vectors a thread may hold in the single-row prologue
+
+template <typename DT, int NS, int CPW, bool HAS_ZC, int PRO>
+__global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel(const BurstParams p) {
+  constexpr int SW = 16 * NS, NE = 4 * NS, QW = 4 * NS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nw = p.nw, nthreads = nw * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int strip = blockIdx.x;
+  const int kq = lane >> 4, ml = lane & 15;
+  const int row0 = blockIdx.z * p.rows_pp;
+  const int Mt = min(p.rows_pp, p.M - row0);
+  const int groups = p.chunks / p.gchunks;
+  const int astride = p.K + 8;  // +16 B per row: rows land on different LDS banks
+
+  float* red = reinterpret_cast<float*>(smem);                                 // [nw][NE][64]
+  uint16_t* sc_l = reinterpret_cast<uint16_t*>(smem + (size_t)nw * NE * 256);  // [groups][SW]
+  uint16_t* zc_l = sc_l + (size_t)groups * SW;                                 // [groups][SW] (HAS_ZC)
+  uint16_t* act = zc_l + (HAS_ZC ? (size_t)groups * SW : 0);                   // [rows_pp][astride]
+
+  const u32x4* wstrip = p.wp + (size_t)strip * p.chunks * NS * 64 + lane;
+  const int cpw_total = CPW * p.bursts;
+  const int cfirst = wave * cpw_total;  // this wave's chunks: [cfirst, cfirst + cpw_total)
+
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+  // ---- requests, oldest first: single-row prologue inputs, scales, then the weight burst
+  const int vecs_row = p.K >> 3;
+  u32x4 xa[BURST_XV], xb[BURST_XV], xw[BURST_XV];
+  const bool single = Mt == 1 && vecs_row <= BURST_XV * nthreads;
+  if (single) {
+    const uint16_t* xr = p.x + (size_t)row0 * p.ldx;
+#pragma unroll
+    for (int i = 0; i < BURST_XV; i++) {
+      const int v = threadIdx.x + i * nthreads;
+      if (v < vecs_row) {
+        xa[i] = *reinterpret_cast<const u32x4*>(xr + 8 * v);
+        if constexpr (PRO == PRO_SILU) xb[i] = *reinterpret_cast<const u32x4*>(xr + p.K + 8 * v);
+        if constexpr (PRO == PRO_ADDNORM) {
+          xb[i] = p.res_in ? *reinterpret_cast<const u32x4*>(p.res_in + (size_t)row0 * p.K + 8 * v)
+                           : u32x4{0u, 0u, 0u, 0u};
+          xw[i] = p.norm_w ? *reinterpret_cast<const u32x4*>(p.norm_w + 8 * v) : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+    }
+  }
+  // strip scales: groups x (SW / 2) dwords, up to SR per thread ahead of the weights
+  constexpr int SD = SW / 2;
+  constexpr int SR = 4;
+  const int sdw = groups * SD;
+  uint32_t s_reg[SR] = {0u, 0u, 0u, 0u}, z_reg[SR] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < SR; i++) {
+    const int d = threadIdx.x + i * nthreads;
+    if (d < sdw) {
+      const size_t off = (size_t)(d / SD) * p.N + (size_t)strip * SW + 2 * (d % SD);
+      s_reg[i] = *reinterpret_cast<const uint32_t*>(p.scales + off);
+      if constexpr (HAS_ZC) z_reg[i] = *reinterpret_cast<const uint32_t*>(p.zc + off);
+    }
+  }
+
+  u32x4 w[CPW][NS];
+  auto issue_chunk = [&](int burst, int i) {
+    const size_t c = (size_t)(cfirst + burst * CPW + i);
+#pragma unroll
+    for (int pl = 0; pl < NS; pl++) w[i][pl] = __builtin_nontemporal_load(wstrip + (c * NS + pl) * 64);
+  };
+#pragma unroll
+  for (int i = 0; i < CPW; i++) issue_chunk(0, i);
+
+  // ---- scales -> LDS (strips with more than SR dwords per thread loop here, behind the burst)
+#pragma unroll
+  for (int i = 0; i < SR; i++) {
+    const int d = threadIdx.x + i * nthreads;
+    if (d < sdw) {
+      reinterpret_cast<uint32_t*>(sc_l)[d] = s_reg[i];
+      if constexpr (HAS_ZC) reinterpret_cast<uint32_t*>(zc_l)[d] = z_reg[i];
+    }
+  }
+  for (int d = threadIdx.x + SR * nthreads; d < sdw; d += nthreads) {
+    const size_t off = (size_t)(d / SD) * p.N + (size_t)strip * SW + 2 * (d % SD);
+    reinterpret_cast<uint32_t*>(sc_l)[d] = *reinterpret_cast<const uint32_t*>(p.scales + off);
+    if constexpr (HAS_ZC) reinterpret_cast<uint32_t*>(zc_l)[d] = *reinterpret_cast<const uint32_t*>(p.zc + off);
+  }
+
+  // ---- prologue: activations of this pass -> LDS in the activation dtype
+  auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
+  auto hi = [](uint32_t u) { return DT::to_f32((uint16_t)(u >> 16)); };
+  if (single) {
+    if constexpr (PRO == PRO_ADDNORM) {
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < BURST_XV; i++) {
+        const int v = threadIdx.x + i * nthreads;
+        if (v < vecs_row) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float a = lo(xa[i][e]), c = hi(xa[i][e]);
+            if (p.res_in) {
+              a = DT::to_f32(DT::from_f32(a + lo(xb[i][e])));
+              c = DT::to_f32(DT::from_f32(c + hi(xb[i][e])));
+            }
+            xa[i][e] = pack2<DT>(a, c);  // z, rounded
+            ss += a * a + c * c;
+          }
+          if (strip == 0 && p.res_out) *reinterpret_cast<u32x4*>(p.res_out + (size_t)row0 * p.K + 8 * v) = xa[i];
+        }
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) red[wave] = ss;
+      __syncthreads();
+      float t = 0.f;
+      for (int i = 0; i < nw; i++) t += red[i];
+      const float rs = rsqrtf(t / (float)p.K + p.eps);
+#pragma unroll
+      for (int i = 0; i < BURST_XV; i++) {
+        const int v = threadIdx.x + i * nthreads;
+        if (v < vecs_row) {
+          u32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float a = lo(xa[i][e]) * rs, c = hi(xa[i][e]) * rs;
+            if (p.norm_w) { a *= lo(xw[i][e]); c *= hi(xw[i][e]); }
+            o[e] = pack2<DT>(a, c);
+          }
+          *reinterpret_cast<u32x4*>(act + 8 * v) = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BURST_XV; i++) {
+        const int v = threadIdx.x + i * nthreads;
+        if (v < vecs_row) {
+          u32x4 o = xa[i];
+          if constexpr (PRO == PRO_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              // silu rounded to the activation dtype before the multiply, as the reference op does
+              const float s0 = DT::to_f32(DT::from_f32(silu_f(lo(xa[i][e])))), s1 = DT::to_f32(DT::from_f32(silu_f(hi(xa[i][e]))));
+              o[e] = pack2<DT>(s0 * lo(xb[i][e]), s1 * hi(xb[i][e]));
+            }
+          }
+          *reinterpret_cast<u32x4*>(act + 8 * v) = o;
+        }
+      }
+    }
+  } else {
+    // several rows (or a very long row): straightforward loops; their loads queue behind the burst
+    for (int mb = 0; mb < Mt; mb += 4) {
+      const int nm = min(4, Mt - mb);
+      float rs[4] = {1.f, 1.f, 1.f, 1.f};
+      if constexpr (PRO == PRO_ADDNORM) {
+        float ss[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int v = threadIdx.x; v < vecs_row; v += nthreads) {
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            if (m < nm) {
+              const size_t off = (size_t)(row0 + mb + m);
+              const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + off * p.ldx + 8 * v);
+              u32x4 rv = u32x4{0u, 0u, 0u, 0u};
+              if (p.res_in) rv = *reinterpret_cast<const u32x4*>(p.res_in + off * p.K + 8 * v);
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                float a = lo(xv[e]), c = hi(xv[e]);
+                if (p.res_in) {
+                  a = DT::to_f32(DT::from_f32(a + lo(rv[e])));
+                  c = DT::to_f32(DT::from_f32(c + hi(rv[e])));
+                }
+                ss[m] += a * a + c * c;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) ss[m] = wave_sum(ss[m]);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+          for (int m = 0; m < 4; m++) red[wave * 4 + m] = ss[m];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          float t = 0.f;
+          for (int i = 0; i < nw; i++) t += red[i * 4 + m];
+          rs[m] = rsqrtf(t / (float)p.K + p.eps);
+        }
+      }
+      for (int idx = threadIdx.x; idx < nm * vecs_row; idx += nthreads) {
+        const int m = idx / vecs_row, v = idx - m * vecs_row;
+        const size_t off = (size_t)(row0 + mb + m);
+        const uint16_t* src = p.x + off * p.ldx + 8 * v;
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(src);
+        u32x4 o = xv;
+        if constexpr (PRO == PRO_SILU) {
+          const u32x4 u = *reinterpret_cast<const u32x4*>(src + p.K);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float s0 = DT::to_f32(DT::from_f32(silu_f(lo(xv[e])))), s1 = DT::to_f32(DT::from_f32(silu_f(hi(xv[e]))));
+            o[e] = pack2<DT>(s0 * lo(u[e]), s1 * hi(u[e]));
+          }
+        }
+        if constexpr (PRO == PRO_ADDNORM) {
+          u32x4 rv = u32x4{0u, 0u, 0u, 0u}, wv = u32x4{0u, 0u, 0u, 0u}, zo;
+          if (p.res_in) rv = *reinterpret_cast<const u32x4*>(p.res_in + off * p.K + 8 * v);
+          if (p.norm_w) wv = *reinterpret_cast<const u32x4*>(p.norm_w + 8 * v);
+          const float r_m = m == 0 ? rs[0] : (m == 1 ? rs[1] : (m == 2 ? rs[2] : rs[3]));
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float a = lo(xv[e]), c = hi(xv[e]);
+            if (p.res_in) {
+              a = DT::to_f32(DT::from_f32(a + lo(rv[e])));
+              c = DT::to_f32(DT::from_f32(c + hi(rv[e])));
+            }
+            zo[e] = pack2<DT>(a, c);
+            a *= r_m;
+            c *= r_m;
+            if (p.norm_w) { a *= lo(wv[e]); c *= hi(wv[e]); }
+            o[e] = pack2<DT>(a, c);
+          }
+          if (strip == 0 && p.res_out) *reinterpret_cast<u32x4*>(p.res_out + off * p.K + 8 * v) = zo;
+        }
+        *reinterpret_cast<u32x4*>(act + (size_t)(mb + m) * astride + 8 * v) = o;
+      }
+      if constexpr (PRO == PRO_ADDNORM) __syncthreads();  // red is reused by the next row group
+    }
+  }
+  __syncthreads();
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+
+  // ---- consume the weight planes in arrival order
+  f32x4 tot[NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) tot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
+  const uint16_t* arow = act + (size_t)min(ml, Mt - 1) * astride + 8 * kq;
+
+  for (int burst = 0; burst < p.bursts; burst++) {
+#pragma unroll
+    for (int i = 0; i < CPW; i++) {
+      const int c = cfirst + burst * CPW + i;
+      f32x4 acc[NS], acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const u32x4 bf = *reinterpret_cast<const u32x4*>(arow + (c * 4 + ks) * 32);
+        acc1 = mfma16<DT>(ones, bf, acc1);
+#pragma unroll
+        for (int sub = 0; sub < NS; sub++) {
+          const int e = ks * NS + sub;
+          acc[sub] = mfma16<DT>(dequant_frag<DT>(w[i][e >> 2][e & 3]), bf, acc[sub]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // dequantised fragments of one k-step live at a time
+      }
+      // this lane's outputs: channels QW kq + 4 sub + r of the strip
+      const int g = c / p.gchunks;
+      const uint16_t* sg = sc_l + (size_t)g * SW + QW * kq;
+      const uint16_t* zg = zc_l + (size_t)g * SW + QW * kq;
+#pragma unroll
+      for (int sub = 0; sub < NS; sub++) {
+        const u32x2 sv = *reinterpret_cast<const u32x2*>(sg + 4 * sub);
+        u32x2 zv = u32x2{0u, 0u};
+        if constexpr (HAS_ZC) zv = *reinterpret_cast<const u32x2*>(zg + 4 * sub);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const uint32_t sw_ = sv[r >> 1];
+          const float s = (r & 1) ? hi(sw_) : lo(sw_);
+          float z;
+          if constexpr (HAS_ZC) z = (r & 1) ? hi(zv[r >> 1]) : lo(zv[r >> 1]);
+          else z = DT::int4_bias + 8.0f;
+          const float d = __builtin_fmaf(-z, acc1[r], acc[sub][r]);
+          tot[sub][r] = __builtin_fmaf(s, d, tot[sub][r]);
+        }
+      }
+      // the slot just consumed is refilled at once: CPW chunks stay in flight per wave to the end
+      if (burst + 1 < p.bursts) issue_chunk(burst + 1, i);
+      // keep the chunks' MFMA chains apart: interleaving them would hold several accumulator sets live
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- cross-wave reduction through LDS, then every (row, 4 channels) item is finished by one thread
+#pragma unroll
+  for (int sub = 0; sub < NS; sub++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[(wave * NE + 4 * sub + r) * 64 + lane] = tot[sub][r];
+  __syncthreads();
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+  for (int it = threadIdx.x; it < Mt * QW; it += nthreads) {
+    const int m_l = it / QW, nq = it % QW;
+    const int nl = 4 * nq;
+    const int src_lane = 16 * (nl / QW) + m_l, e0 = nl % QW;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float s = 0.f;
+      for (int i = 0; i < nw; i++) s += red[(i * NE + e0 + j) * 64 + src_lane];
+      v[j] = s;
+    }
+    const int n = strip * SW + nl;
+    if (p.bias) {  // bias is added to the rounded GEMM result, as output.add_(bias) does
+      const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = DT::to_f32(DT::from_f32(v[j]));
+      v[0] += lo(bb[0]); v[1] += hi(bb[0]); v[2] += lo(bb[1]); v[3] += hi(bb[1]);
+    }
+    u32x2 o;
+    o[0] = pack2<DT>(v[0], v[1]);
+    o[1] = pack2<DT>(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(p.out + (size_t)(row0 + m_l) * p.N + n) = o;
+  }
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+}
+
+// (NS, CPW) pairs the burst kernel is built for
+static bool burst_built(int ns, int cpw) {
+  switch (ns) {
+    case 1: return cpw == 2 || cpw == 4 || cpw == 7;
+    case 2: return cpw == 2 || cpw == 4;
+    case 4: return cpw == 2 || cpw == 4;
+    case 7: return cpw == 2;
+    default: return false;
+  }
+}
+
+struct BurstPlan {
+  bool ok;
+  int nw, cpw, bursts, rows_pp;
+  size_t lds;
+};
+
+// Waves and burst depth for a strip of NS subtiles over K: the most waves (<= 16, <= 8 for the
+// wide strips whose register budget needs 512-thread workgroups) that divide the chunk count
+// with a per-wave share the kernel is built for; rows per pass from what is left of the LDS.
+static BurstPlan plan_burst(int M, int K, int G, int ns, bool has_zc) {
+  BurstPlan bp{false, 0, 0, 0, 0, 0};
+  if (G % 128 || K % 128) return bp;
+  const int chunks = K / 128, groups = K / G;
+  for (int nw = 16; nw >= 2 && !bp.ok; nw--) {
+    if (chunks % nw) continue;
+    const int per = chunks / nw;
+    for (int cpw = 7; cpw >= 2; cpw--) {
+      if (per % cpw || !burst_built(ns, cpw)) continue;
+      if (cpw * ns >= 7 && nw > 8) continue;  // deep rings are built for 512-thread workgroups
+      bp.ok = true; bp.nw = nw; bp.cpw = cpw; bp.bursts = per / cpw;
+      break;
+    }
+  }
+  if (!bp.ok) return bp;
+  const size_t fixed = (size_t)bp.nw * ns * 4 * 256 + (size_t)groups * ns * 16 * 2 * (has_zc ? 2 : 1);
+  const size_t row = (size_t)(K + 8) * 2;
+  if (fixed + row > 160 * 1024) { bp.ok = false; return bp; }
+  bp.rows_pp = (int)std::min<size_t>(16, (160 * 1024 - fixed) / row);
+  bp.rows_pp = std::min(bp.rows_pp, M);
+  bp.lds = fixed + (size_t)bp.rows_pp * row;
+  return bp;
+}
+
+template <typename DT, int NS, int CPW, int PRO>
+static int launch_burst2(const BurstParams& p, size_t lds, hipStream_t stream) {
+  dim3 grid(p.N / (16 * NS), 1, (p.M + p.rows_pp - 1) / p.rows_pp), block(p.nw * 64);
+  if (p.zc)
+    hipLaunchKernelGGL((w4a16_burst_kernel<DT, NS, CPW, true, PRO>), grid, block, lds, stream, p);
+  else
+    hipLaunchKernelGGL((w4a16_burst_kernel<DT, NS, CPW, false, PRO>), grid, block, lds, stream, p);
+  return check_launch("w4a16_burst_kernel");
+}
+
+template <typename DT, int PRO>
+static int launch_burst(const BurstParams& p, int ns, int cpw, size_t lds, hipStream_t stream) {
+#define MI355Q_B(n, c) if (ns == n && cpw == c) return launch_burst2<DT, n, c, PRO>(p, lds, stream)
+  MI355Q_B(1, 2); MI355Q_B(1, 4); MI355Q_B(1, 7);
+  MI355Q_B(2, 2); MI355Q_B(2, 4);
+  MI355Q_B(4, 2); MI355Q_B(4, 4);
+  MI355Q_B(7, 2);
+#undef MI355Q_B
+  return set_error(MI355Q_EINVAL, "w4a16_gemm: no burst kernel for strip %d, depth %d", 16 * ns, cpw);
+}
+
 // The ticket counters occupy a fixed block at the start of the workspace, so that partial
 // tiles of one GEMM shape can never land on the counters of another.
 constexpr size_t COUNTER_BYTES = 64 * 1024;
@@ -704,7 +1149,7 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
                      void* workspace, size_t workspace_bytes, int split_k, hipStream_t stream,
                      int pro, const NormArgs* na, const MoeArgs* moe = nullptr) {
   if (int e = check_shape(K, N, G)) return e;
-  if (int e = check_tile(sw, K, G)) return e;
+  if (int e = check_tile(sw, K, G, N)) return e;
   MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w4a16_gemm: act_dtype must be bf16 or fp16");
   if (M == 0) return MI355Q_OK;
   MI355Q_REQUIRE(x && packed && scales && c, "w4a16_gemm: null pointer");
@@ -713,6 +1158,41 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
   MI355Q_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)scales & 15) == 0 &&
                      ((uintptr_t)c & 7) == 0 && ((uintptr_t)zc & 15) == 0 && ((uintptr_t)bias & 7) == 0,
                  "w4a16_gemm: pointers must be 16-byte aligned");
+  // decode path: one burst workgroup per strip whenever the strips alone occupy the chip
+  if (!moe) {
+    const int ns = sw / 16;
+    const BurstPlan bp = plan_burst(M, K, G, ns, zc != nullptr);
+    const char* nb = getenv("MI355Q_NO_BURST");
+    const bool want_split = split_k > 1 || (N / sw) * ((M + 15) / 16) < 128;
+    if (bp.ok && !(nb && atoi(nb)) && (!legacy_tile(sw) || !want_split)) {
+      BurstParams b;
+      b.x = (const uint16_t*)x; b.ldx = ldx; b.wp = (const u32x4*)packed;
+      b.scales = (const uint16_t*)scales; b.zc = (const uint16_t*)zc; b.bias = (const uint16_t*)bias;
+      b.out = (uint16_t*)c;
+      b.res_in = nullptr; b.res_out = nullptr; b.norm_w = nullptr; b.eps = 0.f;
+      if (pro == PRO_ADDNORM) {
+        MI355Q_REQUIRE(na && na->res_out, "w4a16_gemm_add_rms_norm: residual_out is required");
+        MI355Q_REQUIRE(((uintptr_t)na->res_in & 15) == 0 && ((uintptr_t)na->res_out & 15) == 0 && ((uintptr_t)na->norm_w & 15) == 0,
+                       "w4a16_gemm_add_rms_norm: pointers must be 16-byte aligned");
+        MI355Q_REQUIRE(na->res_out != na->res_in && na->res_out != x, "w4a16_gemm_add_rms_norm: residual_out must not alias an input");
+        b.res_in = (const uint16_t*)na->res_in; b.res_out = (uint16_t*)na->res_out;
+        b.norm_w = (const uint16_t*)na->norm_w; b.eps = na->eps;
+      }
+      b.M = M; b.N = N; b.K = K; b.chunks = K / 128; b.gchunks = G / 128;
+      b.rows_pp = bp.rows_pp; b.nw = bp.nw; b.bursts = bp.bursts;
+      b.stamps = g_burst_stamps;
+#define MI355Q_BPRO(DTT)                                                                       \
+  switch (pro) {                                                                               \
+    case PRO_SILU: return launch_burst<DTT, PRO_SILU>(b, ns, bp.cpw, bp.lds, stream);          \
+    case PRO_ADDNORM: return launch_burst<DTT, PRO_ADDNORM>(b, ns, bp.cpw, bp.lds, stream);    \
+    default: return launch_burst<DTT, PRO_NONE>(b, ns, bp.cpw, bp.lds, stream);                \
+  }
+      if (act_dtype == MI355Q_BF16) { MI355Q_BPRO(BF16) }
+      MI355Q_BPRO(FP16)
+#undef MI355Q_BPRO
+    }
+  }
+  MI355Q_REQUIRE(legacy_tile(sw), "w4a16_gemm: strip width %d needs a group size that is a multiple of 128 and K = 128 * waves * {2,4,7}", sw);
   const int CS = chunk_steps(G);
   SkinnyParams p;
   p.x = (const uint16_t*)x;
@@ -850,7 +1330,7 @@ extern "C" int mi355q_w4a16_dequantize(const void* packed, const void* scales, c
                                        void* w, int K, int N, int G, int tile, int act_dtype,
                                        mi355q_stream_t stream) {
   if (int e = check_shape(K, N, G)) return e;
-  if (int e = check_tile(tile, K, G)) return e;
+  if (int e = check_tile(tile, K, G, N)) return e;
   MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w4a16_dequantize: act_dtype must be bf16 or fp16");
   MI355Q_REQUIRE(packed && scales && w, "w4a16_dequantize: null pointer");
   const size_t nd = (size_t)K * N / 8;
@@ -876,3 +1356,30 @@ extern "C" int mi355q_moe_w4a16_gemm(const void* x, int ldx, int x_row_div, cons
   return gemm_impl(x, ldx, packed, scales, zc, nullptr, c, slots, N, K, G, tile, act_dtype, nullptr, 0, 1,
                    (hipStream_t)stream, fuse_silu_mul ? PRO_SILU : PRO_NONE, nullptr, &moe);
 }
+
+// Strip width for decode: strips of 16 NS channels such that the layer gives about one
+// workgroup per CU in as few rounds as possible (estimate: rounds x (fixed cost + strip bytes at
+// the per-CU ingest rate)).  Only widths the burst kernel is built for are considered; layers
+// with too few strips to occupy the chip keep the widths of the split-K capable kernel.
+extern "C" int mi355q_w4a16_choose_strip(int K, int N, int G) {
+  if (G <= 0) G = K;
+  const int legacy = mi355q_w4a16_choose_tile(K, N, G);
+  if (getenv("MI355Q_TILE") || G % 128 || K % 128) return legacy;
+  int best = 0;
+  double best_cost = 1e30;
+  const int cands[4] = {1, 2, 4, 7};
+  for (int ns : cands) {
+    const int sw = 16 * ns;
+    if (N % sw || !tile_ok(sw, K, G) || !plan_burst(1, K, G, ns, false).ok) continue;
+    const int blocks = N / sw;
+    if (blocks < 128) continue;
+    const int rounds = (blocks + 255) / 256;
+    const double cost = rounds * (3.0 + (double)K * sw / 2 / 24e3);  // us; 24 GB/s per CU ~ 10 B/cycle
+    if (cost < best_cost) { best_cost = cost; best = sw; }
+  }
+  return best ? best : legacy;
+}
+
+/* Diagnostics: when set, every burst-kernel workgroup writes four 100 MHz timestamps (entry,
+ * activations staged, weights consumed, done) at stamps[4 * strip ..].  Not part of the public ABI. */
+extern "C" void mi355q_debug_burst_stamps(void* stamps) { g_burst_stamps = (unsigned long long*)stamps; }

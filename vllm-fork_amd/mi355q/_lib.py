@@ -27,6 +27,7 @@ _SIGS = {
     "mi355q_last_error": (ctypes.c_char_p, []),
     "mi355q_version": (c_int, []),
     "mi355q_w4a16_choose_tile": (c_int, [c_int, c_int, c_int]),
+    "mi355q_w4a16_choose_strip": (c_int, [c_int, c_int, c_int]),
     "mi355q_w4a16_repack": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_w4a16_repack_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mi355q_w4a16_unpack_host": (c_int, [c_vp, c_vp, c_int, c_int, c_int]),

@@ -73,7 +73,7 @@ def w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tens
         zc = torch.empty((K // G, N), dtype=scales.dtype, device=qweight.device)
     L = _lib.lib()
     if tile == 0:
-        tile = L.mi355q_w4a16_choose_tile(K, N, G)
+        tile = L.mi355q_w4a16_choose_strip(K, N, G)
     if qweight.is_cuda:
         check(L.mi355q_w4a16_repack(qweight.data_ptr(), _ptr(qzeros if zc is not None else None),
                                     packed.data_ptr(), _ptr(zc), K, N, G, tile, src_layout, zp_mode, act, _stream()))
