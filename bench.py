@@ -72,7 +72,7 @@ def time_dominant_kernel(runner, batch, reps=6):
     nbytes = w4a16_bytes(batch, K, N, runner.G, runner.quant == "awq")
     return {"bound": "hbm", "achieved": nbytes / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": nbytes / avg / 1e9 / HBM_PEAK_GBS, "traffic": None,
-            "kernel": "w4a16_skinny_kernel (gate_up_proj %dx%d, M=%d)" % (K, N, batch),
+            "kernel": "w4a16_burst_kernel (gate_up_proj %dx%d + add/RMSNorm prologue + SiLU epilogue, M=%d)" % (K, N, batch),
             "bytes_per_launch": nbytes, "avg_launch_us": avg * 1e6, "min_launch_us": min(times) * 1e6,
             "launches": len(times)}
 

@@ -42,6 +42,11 @@ enum {
   MI355Q_W_NSEQ = 1, /* int32 [K, N/8], 8 consecutive n per word (triton_w4a16.py:368-389) */
   MI355Q_W_AWQ = 2   /* int32 [K, N/8], AWQ nibble order (auto_awq.py:478-515) */
 };
+/* OR-ed into src_layout: the packed matrix interleaves the two halves of the checkpoint's
+ * output channels (packed column 2i = column i, 2i+1 = column N/2 + i), i.e. gate_i and up_i
+ * of a merged gate_up projection (linear.py:661-1020) side by side.  The caller permutes the
+ * scales the same way; zc comes out permuted. */
+enum { MI355Q_W_PAIR_HALVES = 0x100 };
 
 /* zero-point conventions accepted by the repack */
 enum {
@@ -158,6 +163,23 @@ int mi355q_w4a16_gemm_add_rms_norm(const void* x, int ldx, const void* residual_
                                    const void* bias, void* c, int M, int N, int K, int G, int tile,
                                    int act_dtype, void* workspace, size_t workspace_bytes,
                                    int split_k, mi355q_stream_t stream);
+
+/*
+ * gate_up projection with SiluAndMul in its epilogue, for weights repacked with
+ * MI355Q_W_PAIR_HALVES: c[M, N/2] = silu(y[:, 2i]) * y[:, 2i+1] with y = the GEMM above
+ * (rounded to act_dtype first, silu rounded before the multiply: the arithmetic of
+ * torch.ops._C.silu_and_mul on the projection output, activation_kernels.cu:98-155).
+ * residual_out != NULL additionally runs the add + RMSNorm prologue of
+ * mi355q_w4a16_gemm_add_rms_norm; residual_out == NULL takes x as is.  The down projection
+ * then reads N/2 activations per row instead of N.  Needs a layer the burst kernel serves
+ * (group size a multiple of 128, N / tile >= 128); returns MI355Q_EINVAL otherwise.
+ */
+/* 1 when mi355q_w4a16_gate_up_silu can serve a [K, N] layer repacked with this tile width. */
+int mi355q_w4a16_gate_up_silu_supported(int K, int N, int G, int tile);
+int mi355q_w4a16_gate_up_silu(const void* x, int ldx, const void* residual_in, void* residual_out,
+                              const void* norm_weight, float epsilon, const void* packed,
+                              const void* scales, const void* zc, void* c, int M, int N, int K, int G,
+                              int tile, int act_dtype, mi355q_stream_t stream);
 
 /* W[K,N] (act_dtype) = (q - z) * s.  Replaces ops.awq_dequantize
  * (vllm/_custom_ops.py:491-505; awq/gemm_kernels.cu:414-464). */

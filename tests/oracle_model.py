@@ -21,8 +21,27 @@ def _gemm(lin, x):
                           zp_mode=orc.ZP_AWQ)
 
 
-def oracle_generate(runner, prompt, n_new):
-    """Returns [[tok per sequence] for each of n_new generated positions]."""
+def assert_tokens_match(got, want, logits):
+    """got/want: [step][sequence] token ids; logits: [step][sequence] fp32 oracle logits.  Tokens must
+    agree, except that a sequence may leave the oracle's path at a near-tie: fp32 sums are not
+    associative, so a logit pair closer than two 16-bit ulps may order either way.  After such a
+    step the sequence has a different history and is no longer compared."""
+    B = len(want[0])
+    for b in range(B):
+        for i in range(len(want)):
+            g, w = got[i][b], want[i][b]
+            if g == w:
+                continue
+            lg = logits[i][b]
+            tol = 2.0 ** -6 * max(abs(float(lg[w])), 1e-3)
+            assert float(lg[w] - lg[g]) <= tol, (
+                f"sequence {b} step {i}: token {g} instead of {w}; oracle logits {lg[g]} vs {lg[w]}")
+            break
+
+
+def oracle_generate(runner, prompt, n_new, with_logits=False):
+    """Returns [[tok per sequence] for each of n_new generated positions] (and, with_logits, the
+    fp32 logits behind every one of them in the same nesting)."""
     cfg = runner.cfg
     B, T = prompt.shape
     D, H, KVH = cfg.head_dim, runner.heads, runner.kv_heads
@@ -62,15 +81,16 @@ def oracle_generate(runner, prompt, n_new):
             h = _gemm(L["down"], orc.silu_and_mul(gu))
         hn, _ = orc.fused_add_rms_norm(h, residual, _bits(runner.norm), eps)
         logits = orc.linear_h16(hn, lm_head)
-        return int(orc.argmax_h16(logits)[0])
+        return int(orc.argmax_h16(logits)[0]), orc.h16_to_f32(logits[0])
 
     out = [[0] * B for _ in range(n_new)]
+    lgs = [[None] * B for _ in range(n_new)]
     for b in range(B):
-        nxt = None
+        nxt = lg = None
         for pos in range(T):
-            nxt = step(b, int(prompt[b, pos]), pos)
-        out[0][b] = nxt
+            nxt, lg = step(b, int(prompt[b, pos]), pos)
+        out[0][b], lgs[0][b] = nxt, lg
         for i in range(1, n_new):
-            nxt = step(b, nxt, T + i - 1)
-            out[i][b] = nxt
-    return out
+            nxt, lg = step(b, nxt, T + i - 1)
+            out[i][b], lgs[i][b] = nxt, lg
+    return (out, lgs) if with_logits else out

@@ -5,23 +5,27 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("quant,kv", [("gptq", "auto"), ("awq", "fp8"), ("gptq", "fp8")])
-def test_greedy_tokens_match_oracle(quant, kv, monkeypatch):
+@pytest.mark.parametrize("quant,kv,model", [("gptq", "auto", "tiny"), ("awq", "fp8", "tiny"), ("gptq", "fp8", "tiny"),
+                                            ("gptq", "auto", "small"), ("awq", "fp8", "small")])
+def test_greedy_tokens_match_oracle(quant, kv, model, monkeypatch):
     from mi355q import ops
     from mi355q.model import CONFIGS, LlamaRunner
-    from oracle_model import oracle_generate
+    from oracle_model import assert_tokens_match, oracle_generate
     # keep prompt processing on the fp32-dequant kernels, whose arithmetic the oracle restates
     monkeypatch.setattr(ops, "DEQUANT_MATMUL_MIN_TOKENS", 1 << 30)
-    cfg = CONFIGS["tiny"]
+    cfg = CONFIGS[model]   # "small" is wide enough for the burst kernels and the fused gate_up + SiLU
     runner = LlamaRunner(cfg, quant=quant, kv_cache_dtype=kv, device="cuda:0", max_batch=2, max_seq_len=64,
                          keep_checkpoint=True, seed=3)
+    assert runner.layers[0]["gate_up"].w.pair_halves == (model == "small")
     prompt = torch.randint(0, cfg.vocab, (2, 21), generator=torch.Generator().manual_seed(1))
     got = [runner.prefill(prompt).cpu().tolist()]
     runner.capture()
     for _ in range(5):
         runner.decode_step()
         got.append(runner.tokens.cpu().tolist())
-    assert got == oracle_generate(runner, prompt, 6)
+    want, logits = oracle_generate(runner, prompt, 6, with_logits=True)
+    assert_tokens_match(got, want, logits)
+    assert got[0] == want[0] and sum(g == w for g, w in zip(got, want)) >= 4
 
 
 def test_graph_and_eager_decode_agree():

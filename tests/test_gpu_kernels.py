@@ -727,3 +727,48 @@ def test_moe_expert_map_and_sum():
     s = torch.empty((T, H), dtype=torch.bfloat16, device=DEV)
     ops.moe_sum(y, s)
     assert torch.equal(s, y.float().sum(1).to(torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------
+# gate_up projection with SiluAndMul in its epilogue (pair_halves layout)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,I,awq,norm", [(1, 4096, 14336, False, True), (2, 1024, 2048, True, True),
+                                           (5, 512, 1024, False, False), (1, 8192, 3584, False, True)])
+def test_w4a16_gate_up_silu(M, K, I, awq, norm):
+    """= fused_add_rms_norm -> gate_up GEMM -> silu_and_mul of the oracle, with the two halves of
+    the checkpoint's output channels interleaved at repack time."""
+    rng = np.random.default_rng(K + I)
+    G, N = 128, 2 * I
+    assert ops.w4a16_gate_up_silu_supported(K, N, G)
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    s = orc.f32_to_h16((0.03 * rng.random((K // G, N)) + 0.005).astype(np.float32))
+    x = orc.f32_to_h16(rng.standard_normal((M, K)).astype(np.float32))
+    r = orc.f32_to_h16(rng.standard_normal((M, K)).astype(np.float32))
+    nw = orc.f32_to_h16((1 + 0.1 * rng.standard_normal(K)).astype(np.float32))
+    if awq:
+        z = rng.integers(0, 16, size=(K // G, N), dtype=np.int32)
+        qw, qz = orc.pack_cols(q, awq_order=True), orc.pack_cols(z, awq_order=True)
+        w = ops.w4a16_repack(i32(qw), to_dev(s), i32(qz), G, _lib.W_AWQ, _lib.ZP_AWQ, pair_halves=True)
+        kw = dict(layout=orc.W_AWQ, zp_mode=orc.ZP_AWQ)
+    else:
+        qw, qz = orc.gptq_pack(q), None
+        w = ops.w4a16_repack(i32(qw), to_dev(s), None, G, pair_halves=True)
+        kw = {}
+    if norm:
+        xn, rn = orc.fused_add_rms_norm(x, r, nw, 1e-5)
+    else:
+        xn, rn = x, None
+    y = orc.w4a16_gemm(xn, qw, s, qz, None, G=G, **kw)
+    ref = orc.silu_and_mul(y)
+    act, res = ops.w4a16_gate_up_silu(to_dev(x), to_dev(r) if norm else None, to_dev(nw) if norm else None, 1e-5, w,
+                                      add_norm=norm)
+    assert act.shape == (M, I)
+    np.testing.assert_allclose(f32(to_bits(act)), f32(ref), rtol=2e-2, atol=1e-2)
+    assert (to_bits(act) == ref).mean() > 0.97
+    if norm:
+        assert np.array_equal(to_bits(res), rn)
+    # the same weight through the plain GEMM gives the interleaved projection output
+    plain = ops.unpair_halves(ops.w4a16_gemm(to_dev(xn), w))
+    assert (to_bits(plain) == y).mean() > 0.98
+    deq = ops.unpair_halves(ops.w4a16_dequantize(w))
+    assert np.array_equal(to_bits(deq), orc.f32_to_h16(orc.w4a16_dequant(qw, s, qz, G=G, **kw)))

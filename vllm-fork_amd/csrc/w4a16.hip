@@ -99,10 +99,19 @@ __host__ __device__ static inline void dword_pos(int K, int sw, size_t d, int* k
   *k0 = 32 * kstep + 8 * kq;
 }
 
+// With MI355Q_W_PAIR_HALVES, packed column n holds checkpoint column n/2 of the first half
+// (n even) or of the second half (n odd): gate_i and up_i of a merged gate_up projection
+// become neighbours, so one workgroup can finish silu(gate_i) * up_i in its epilogue.
+__host__ __device__ static inline int pair_src(int n, int N, int layout) {
+  return (layout & MI355Q_W_PAIR_HALVES) ? (n >> 1) + ((n & 1) ? (N >> 1) : 0) : n;
+}
+
 __host__ __device__ static inline uint32_t repack_dword(const int32_t* qw, int layout, int K, int N,
                                                         int sw, size_t d) {
   int k0, n;
   dword_pos(K, sw, d, &k0, &n);
+  n = pair_src(n, N, layout);
+  layout &= 0xff;
   uint32_t w = 0;
   if (layout == MI355Q_W_GPTQ) {
     const uint32_t s = (uint32_t)qw[(size_t)(k0 >> 3) * N + n];
@@ -116,7 +125,8 @@ __host__ __device__ static inline uint32_t repack_dword(const int32_t* qw, int l
 }
 
 __host__ __device__ static inline uint16_t repack_zc(const int32_t* qz, int zp_mode, int N, int g,
-                                                     int n, int act_dtype) {
+                                                     int n, int act_dtype, int layout) {
+  n = pair_src(n, N, layout);
   const int pos = zp_mode == MI355Q_ZP_AWQ ? awq_pos(n) : (n & 7);
   uint32_t z = ((uint32_t)qz[(size_t)g * (N >> 3) + (n >> 3)] >> (4 * pos)) & 0xfu;
   if (zp_mode == MI355Q_ZP_GPTQ_V1) z = (z + 1) & 0x1fu;
@@ -132,11 +142,11 @@ __global__ void repack_weight_kernel(const int32_t* __restrict__ qw, uint32_t* _
 }
 
 __global__ void repack_zc_kernel(const int32_t* __restrict__ qz, uint16_t* __restrict__ zc, int N,
-                                 int groups, int zp_mode, int act_dtype) {
+                                 int groups, int zp_mode, int act_dtype, int layout) {
   const size_t total = (size_t)groups * N;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
        e += (size_t)gridDim.x * blockDim.x)
-    zc[e] = repack_zc(qz, zp_mode, N, (int)(e / N), (int)(e % N), act_dtype);
+    zc[e] = repack_zc(qz, zp_mode, N, (int)(e / N), (int)(e % N), act_dtype, layout);
 }
 
 static inline int chunk_steps(int G) { return (G % 128 == 0) ? 4 : (G % 64 == 0) ? 2 : 1; }
@@ -169,7 +179,8 @@ static int check_tile(int sw, int K, int G, int N = 0) {
 
 static int check_enums(int src_layout, int zp_mode, int act_dtype, const void* qzeros,
                        const void* zc) {
-  MI355Q_REQUIRE(src_layout >= MI355Q_W_GPTQ && src_layout <= MI355Q_W_AWQ, "w4a16: bad src_layout %d", src_layout);
+  MI355Q_REQUIRE((src_layout & 0xff) >= MI355Q_W_GPTQ && (src_layout & 0xff) <= MI355Q_W_AWQ &&
+                     (src_layout & ~0x1ff) == 0, "w4a16: bad src_layout %d", src_layout);
   MI355Q_REQUIRE(zp_mode >= MI355Q_ZP_CONST && zp_mode <= MI355Q_ZP_GPTQ_V1, "w4a16: bad zp_mode %d", zp_mode);
   MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w4a16: act_dtype must be bf16 or fp16");
   if (zp_mode != MI355Q_ZP_CONST)
@@ -210,7 +221,7 @@ extern "C" int mi355q_w4a16_repack(const int32_t* qweight, const int32_t* qzeros
     const size_t nz = (size_t)(K / G) * N;
     const int gz = (int)((nz + 255) / 256 < 4096 ? (nz + 255) / 256 : 4096);
     hipLaunchKernelGGL(repack_zc_kernel, dim3(gz), dim3(256), 0, (hipStream_t)stream, qzeros,
-                       (uint16_t*)zc, N, K / G, zp_mode, act_dtype);
+                       (uint16_t*)zc, N, K / G, zp_mode, act_dtype, src_layout);
     if (int e = check_launch("repack_zc_kernel")) return e;
   }
   return MI355Q_OK;
@@ -229,7 +240,7 @@ extern "C" int mi355q_w4a16_repack_host(const int32_t* qweight, const int32_t* q
   if (zp_mode != MI355Q_ZP_CONST) {
     uint16_t* z = (uint16_t*)zc;
     for (int g = 0; g < K / G; g++)
-      for (int n = 0; n < N; n++) z[(size_t)g * N + n] = repack_zc(qzeros, zp_mode, N, g, n, act_dtype);
+      for (int n = 0; n < N; n++) z[(size_t)g * N + n] = repack_zc(qzeros, zp_mode, N, g, n, act_dtype, src_layout);
   }
   return MI355Q_OK;
 }
@@ -681,6 +692,7 @@ struct BurstParams {
   int rows_pp;  // activation rows per pass
   int nw;       // waves per workgroup; chunks == nw * CPW * bursts
   int bursts;
+  int epi_silu;  // 1: channels are (gate, up) pairs; write silu(gate) * up, N / 2 values per row
   unsigned long long* stamps;  // diagnostics: 4 x 100 MHz timestamps per workgroup, or null
 };
 
@@ -992,10 +1004,18 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
       for (int j = 0; j < 4; j++) v[j] = DT::to_f32(DT::from_f32(v[j]));
       v[0] += lo(bb[0]); v[1] += hi(bb[0]); v[2] += lo(bb[1]); v[3] += hi(bb[1]);
     }
-    u32x2 o;
-    o[0] = pack2<DT>(v[0], v[1]);
-    o[1] = pack2<DT>(v[2], v[3]);
-    *reinterpret_cast<u32x2*>(p.out + (size_t)(row0 + m_l) * p.N + n) = o;
+    if (p.epi_silu) {
+      // SiluAndMul on the rounded projection outputs: round(round(silu(g)) * u), as the separate op does
+      const float g0 = DT::to_f32(DT::from_f32(v[0])), u0 = DT::to_f32(DT::from_f32(v[1]));
+      const float g1 = DT::to_f32(DT::from_f32(v[2])), u1 = DT::to_f32(DT::from_f32(v[3]));
+      const float s0 = DT::to_f32(DT::from_f32(silu_f(g0))), s1 = DT::to_f32(DT::from_f32(silu_f(g1)));
+      *reinterpret_cast<uint32_t*>(p.out + (size_t)(row0 + m_l) * (p.N >> 1) + (n >> 1)) = pack2<DT>(s0 * u0, s1 * u1);
+    } else {
+      u32x2 o;
+      o[0] = pack2<DT>(v[0], v[1]);
+      o[1] = pack2<DT>(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(p.out + (size_t)(row0 + m_l) * p.N + n) = o;
+    }
   }
   if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
 }
@@ -1147,7 +1167,7 @@ struct MoeArgs {
 static int gemm_impl(const void* x, int ldx, const void* packed, const void* scales, const void* zc,
                      const void* bias, void* c, int M, int N, int K, int G, int sw, int act_dtype,
                      void* workspace, size_t workspace_bytes, int split_k, hipStream_t stream,
-                     int pro, const NormArgs* na, const MoeArgs* moe = nullptr) {
+                     int pro, const NormArgs* na, const MoeArgs* moe = nullptr, int epi_silu = 0) {
   if (int e = check_shape(K, N, G)) return e;
   if (int e = check_tile(sw, K, G, N)) return e;
   MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w4a16_gemm: act_dtype must be bf16 or fp16");
@@ -1163,7 +1183,7 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
     const int ns = sw / 16;
     const BurstPlan bp = plan_burst(M, K, G, ns, zc != nullptr);
     const char* nb = getenv("MI355Q_NO_BURST");
-    const bool want_split = split_k > 1 || (N / sw) * ((M + 15) / 16) < 128;
+    const bool want_split = !epi_silu && (split_k > 1 || (N / sw) * ((M + 15) / 16) < 128);
     if (bp.ok && !(nb && atoi(nb)) && (!legacy_tile(sw) || !want_split)) {
       BurstParams b;
       b.x = (const uint16_t*)x; b.ldx = ldx; b.wp = (const u32x4*)packed;
@@ -1181,6 +1201,8 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
       b.M = M; b.N = N; b.K = K; b.chunks = K / 128; b.gchunks = G / 128;
       b.rows_pp = bp.rows_pp; b.nw = bp.nw; b.bursts = bp.bursts;
       b.stamps = g_burst_stamps;
+      b.epi_silu = epi_silu;
+      MI355Q_REQUIRE(!epi_silu || bias == nullptr, "w4a16_gemm: the SiLU-pair epilogue takes no bias");
 #define MI355Q_BPRO(DTT)                                                                       \
   switch (pro) {                                                                               \
     case PRO_SILU: return launch_burst<DTT, PRO_SILU>(b, ns, bp.cpw, bp.lds, stream);          \
@@ -1192,6 +1214,8 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
 #undef MI355Q_BPRO
     }
   }
+  MI355Q_REQUIRE(!epi_silu, "w4a16_gemm: the SiLU-pair epilogue needs a layer the burst kernel serves "
+                            "(group size a multiple of 128, at least 128 strips)");
   MI355Q_REQUIRE(legacy_tile(sw), "w4a16_gemm: strip width %d needs a group size that is a multiple of 128 and K = 128 * waves * {2,4,7}", sw);
   const int CS = chunk_steps(G);
   SkinnyParams p;
@@ -1378,6 +1402,25 @@ extern "C" int mi355q_w4a16_choose_strip(int K, int N, int G) {
     if (cost < best_cost) { best_cost = cost; best = sw; }
   }
   return best ? best : legacy;
+}
+
+extern "C" int mi355q_w4a16_gate_up_silu(const void* x, int ldx, const void* residual_in,
+                                         void* residual_out, const void* norm_weight, float epsilon,
+                                         const void* packed, const void* scales, const void* zc, void* c,
+                                         int M, int N, int K, int G, int tile, int act_dtype,
+                                         mi355q_stream_t stream) {
+  if (residual_out == nullptr)   // no norm in front: plain GEMM + SiLU-pair epilogue
+    return gemm_impl(x, ldx, packed, scales, zc, nullptr, c, M, N, K, G, tile, act_dtype, nullptr, 0, 0,
+                     (hipStream_t)stream, PRO_NONE, nullptr, nullptr, 1);
+  NormArgs na{residual_in, residual_out, norm_weight, epsilon};
+  return gemm_impl(x, ldx, packed, scales, zc, nullptr, c, M, N, K, G, tile, act_dtype, nullptr, 0, 0,
+                   (hipStream_t)stream, PRO_ADDNORM, &na, nullptr, 1);
+}
+
+extern "C" int mi355q_w4a16_gate_up_silu_supported(int K, int N, int G, int tile) {
+  if (G <= 0) G = K;
+  if (K <= 0 || N <= 0 || N % 64 || tile <= 0 || N % tile || !tile_ok(tile, K, G)) return 0;
+  return plan_burst(1, K, G, tile / 16, false).ok ? 1 : 0;
 }
 
 /* Diagnostics: when set, every burst-kernel workgroup writes four 100 MHz timestamps (entry,

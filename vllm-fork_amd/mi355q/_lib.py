@@ -14,6 +14,7 @@ HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "mi355
 OK, EINVAL, ENOSPACE, EHIP = 0, -1, -2, -3
 BF16, FP16, FP32 = 0, 1, 2
 W_GPTQ, W_NSEQ, W_AWQ = 0, 1, 2
+W_PAIR_HALVES = 0x100
 ZP_CONST, ZP_NSEQ, ZP_AWQ, ZP_GPTQ_V1 = 0, 1, 2, 3
 PA_PARTITION = 256
 
@@ -41,6 +42,9 @@ _SIGS = {
     "mi355q_w4a16_gemm_silu_mul": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int,
                                            c_int, c_int, c_int, c_vp, c_sz, c_int, c_vp]),
     "mi355q_w4a16_dequantize": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_w4a16_gate_up_silu": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp,
+                                          c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_w4a16_gate_up_silu_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "mi355q_topk_softmax": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_moe_w4a16_gemm": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_vp]),

@@ -33,6 +33,7 @@ CONFIGS = {
     "llama3-8b": LlamaConfig("llama3-8b", 4096, 14336, 32, 32, 8, 128, 128256),
     "llama3-70b": LlamaConfig("llama3-70b", 8192, 28672, 80, 64, 8, 128, 128256),
     "tiny": LlamaConfig("tiny", 256, 512, 2, 4, 2, 64, 1024, max_pos=512),
+    "small": LlamaConfig("small", 1024, 2048, 2, 8, 2, 128, 2048, max_pos=512),
 }
 
 
@@ -68,7 +69,8 @@ def decode_bytes_per_step(cfg: LlamaConfig, batch: int, ctx: int, G: int, zeros:
 class Linear4:
     """One quantized projection: checkpoint-layout tensors -> kernel layout -> apply."""
 
-    def __init__(self, K, N, G, dtype, device, gen, asym: bool, gain: float = 1.0, keep_checkpoint: bool = False):
+    def __init__(self, K, N, G, dtype, device, gen, asym: bool, gain: float = 1.0, keep_checkpoint: bool = False,
+                 pair_halves: bool = False):
         self.checkpoint = None
         qweight = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=device, generator=gen)
         # (q - 8) has variance 21.25: keep the projection roughly norm-preserving
@@ -77,16 +79,17 @@ class Linear4:
         if asym:  # AWQ checkpoint tensors: N-packed AWQ order + packed zero points
             qweight = qweight.view(-1)[: K * N // 8].view(K, N // 8)
             qzeros = torch.randint(-2**31, 2**31 - 1, (K // G, N // 8), dtype=torch.int32, device=device, generator=gen)
-            self.w = ops.w4a16_repack(qweight, scales, qzeros, G, _lib.W_AWQ, _lib.ZP_AWQ)
+            self.w = ops.w4a16_repack(qweight, scales, qzeros, G, _lib.W_AWQ, _lib.ZP_AWQ, pair_halves=pair_halves)
             if keep_checkpoint:
                 self.checkpoint = ("awq", qweight.cpu(), scales.cpu(), qzeros.cpu(), G)
         else:
-            self.w = ops.w4a16_repack(qweight, scales, None, G, _lib.W_GPTQ, _lib.ZP_CONST)
+            self.w = ops.w4a16_repack(qweight, scales, None, G, _lib.W_GPTQ, _lib.ZP_CONST, pair_halves=pair_halves)
             if keep_checkpoint:
                 self.checkpoint = ("gptq", qweight.cpu(), scales.cpu(), None, G)
 
     def __call__(self, x, fuse_silu_mul=False):
-        return ops.w4a16_gemm(x, self.w, fuse_silu_mul=fuse_silu_mul)
+        y = ops.w4a16_gemm(x, self.w, fuse_silu_mul=fuse_silu_mul)
+        return ops.unpair_halves(y) if self.w.pair_halves else y
 
 
 class Linear16:
@@ -126,10 +129,13 @@ class LlamaRunner:
         self.kv_heads = max(cfg.kv_heads // tp_size, 1)
         D = cfg.head_dim
 
-        def make(K, N, gain=1.0):
+        def make(K, N, gain=1.0, pair_halves=False):
             if quant == "none":
                 return Linear16(K, N, dtype, self.device, gen, gain)
-            return Linear4(K, N, self.G, dtype, self.device, gen, quant == "awq", gain, keep_checkpoint)
+            return Linear4(K, N, self.G, dtype, self.device, gen, quant == "awq", gain, keep_checkpoint, pair_halves)
+
+        # gate_i next to up_i lets the gate_up kernel finish SiluAndMul itself (decode path)
+        pair = quant != "none" and ops.w4a16_gate_up_silu_supported(*shapes["gate_up"], self.G)
 
         self.layers = []
         for _ in range(cfg.layers):
@@ -138,7 +144,7 @@ class LlamaRunner:
                 "ln2": torch.ones(cfg.hidden, dtype=dtype, device=self.device),
                 "qkv": make(*shapes["qkv"]),
                 "o": make(*shapes["o"], gain=0.5),
-                "gate_up": make(*shapes["gate_up"]),
+                "gate_up": make(*shapes["gate_up"], pair_halves=pair),
                 "down": make(*shapes["down"], gain=0.5),
             })
         self.norm = torch.ones(cfg.hidden, dtype=dtype, device=self.device)
@@ -223,6 +229,10 @@ class LlamaRunner:
                                   slot_mapping, self.kv_cache_dtype, self.k_scale, self.v_scale)
             attend(li, q.view(T, self.heads, D), attn)
         o = self._all_reduce(L["o"](attn.view(T, qs)))
+        if fuse_norm and L["gate_up"].w.pair_halves:
+            act, residual = ops.w4a16_gate_up_silu(o, residual, L["ln2"], cfg.rms_eps, L["gate_up"].w)
+            d = self._all_reduce(L["down"](act))
+            return d, residual
         if fuse_norm:
             gu, residual = ops.w4a16_gemm_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps, L["gate_up"].w)
         else:

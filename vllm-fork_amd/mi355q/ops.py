@@ -41,19 +41,21 @@ def _need_cuda(*ts):
 class PackedW4:
     """Kernel-layout 4-bit weight of one linear layer (output of `w4a16_repack`)."""
 
-    __slots__ = ("packed", "scales", "zc", "K", "N", "G", "tile")
+    __slots__ = ("packed", "scales", "zc", "K", "N", "G", "tile", "pair_halves")
 
-    def __init__(self, packed, scales, zc, K, N, G, tile):
+    def __init__(self, packed, scales, zc, K, N, G, tile, pair_halves=False):
         self.packed, self.scales, self.zc, self.K, self.N, self.G, self.tile = packed, scales, zc, K, N, G, tile
+        self.pair_halves = pair_halves
 
 
 def w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor | None,
                  group_size: int, src_layout: int = _lib.W_GPTQ, zp_mode: int = _lib.ZP_CONST,
-                 tile: int = 0) -> PackedW4:
+                 tile: int = 0, pair_halves: bool = False) -> PackedW4:
     """Checkpoint tensors -> kernel layout.  Stands in for
     MPLinearKernel.process_weights_after_loading (mixed_precision/triton_w4a16.py:338-426).
     Works on device tensors (HIP kernel) and on CPU tensors (host arithmetic, for load
-    paths that repack before upload)."""
+    paths that repack before upload).  pair_halves interleaves the two halves of the output
+    channels (a merged gate_up projection: gate_i next to up_i) for `w4a16_gate_up_silu`."""
     if src_layout == _lib.W_GPTQ:
         K, N = qweight.shape[0] * 8, qweight.shape[1]
     else:
@@ -74,13 +76,16 @@ def w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tens
     L = _lib.lib()
     if tile == 0:
         tile = L.mi355q_w4a16_choose_strip(K, N, G)
+    if pair_halves:
+        src_layout |= _lib.W_PAIR_HALVES
+        scales = scales.view(K // G, 2, N // 2).transpose(1, 2).reshape(K // G, N)
     if qweight.is_cuda:
         check(L.mi355q_w4a16_repack(qweight.data_ptr(), _ptr(qzeros if zc is not None else None),
                                     packed.data_ptr(), _ptr(zc), K, N, G, tile, src_layout, zp_mode, act, _stream()))
     else:
         check(L.mi355q_w4a16_repack_host(qweight.data_ptr(), _ptr(qzeros if zc is not None else None),
                                          packed.data_ptr(), _ptr(zc), K, N, G, tile, src_layout, zp_mode, act))
-    return PackedW4(packed, scales.contiguous(), zc, K, N, G, tile)
+    return PackedW4(packed, scales.contiguous(), zc, K, N, G, tile, pair_halves)
 
 
 _WS: dict = {}
@@ -159,6 +164,37 @@ def w4a16_gemm_add_rms_norm(x: torch.Tensor, residual: torch.Tensor | None, norm
         w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc), _ptr(bias), out.data_ptr(), M, w.N, w.K, w.G,
         w.tile, _dt(x), ws.data_ptr(), ws.numel(), split_k, _stream()))
     return out.reshape(x.shape[:-1] + (w.N,)), res_out.reshape(x.shape)
+
+
+def w4a16_gate_up_silu(x: torch.Tensor, residual: torch.Tensor | None, norm_weight: torch.Tensor | None,
+                       epsilon: float, w: PackedW4, add_norm: bool = True):
+    """[fused_add_rms_norm ->] gate_up projection -> SiluAndMul in one kernel, for a weight repacked with
+    pair_halves.  Returns (activation [tokens, N/2], new residual or None)."""
+    _need_cuda(x, w.packed)
+    if not w.pair_halves:
+        raise RuntimeError("w4a16_gate_up_silu needs a weight repacked with pair_halves=True")
+    x2 = x.reshape(-1, w.K)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    out = torch.empty((M, w.N // 2), dtype=x.dtype, device=x.device)
+    res_out = torch.empty((M, w.K), dtype=x.dtype, device=x.device) if add_norm else None
+    check(_lib.lib().mi355q_w4a16_gate_up_silu(
+        x2.data_ptr(), x2.stride(0), _ptr(residual), _ptr(res_out), _ptr(norm_weight), epsilon, w.packed.data_ptr(),
+        w.scales.data_ptr(), _ptr(w.zc), out.data_ptr(), M, w.N, w.K, w.G, w.tile, _dt(x), _stream()))
+    return out.reshape(x.shape[:-1] + (w.N // 2,)), (None if res_out is None else res_out.reshape(x.shape))
+
+
+def w4a16_gate_up_silu_supported(K: int, N: int, group_size: int) -> bool:
+    """Can a [K, N] gate_up layer take the pair_halves layout and the fused kernel?"""
+    L = _lib.lib()
+    G = K if group_size in (-1, 0) else group_size
+    return bool(L.mi355q_w4a16_gate_up_silu_supported(K, N, G, L.mi355q_w4a16_choose_strip(K, N, G)))
+
+
+def unpair_halves(y: torch.Tensor) -> torch.Tensor:
+    """Output of a pair_halves projection [.., N] (g0, u0, g1, u1, ...) -> (g | u) halves."""
+    return torch.cat((y[..., 0::2], y[..., 1::2]), dim=-1)
 
 
 def w4a16_dequantize(w: PackedW4) -> torch.Tensor:
