@@ -54,8 +54,18 @@ def time_dominant_kernel(runner, batch, reps=6):
     K, N = linear_shapes(runner.cfg, runner.tp_size)["gate_up"]
     x = (torch.randn((batch, K), device=runner.device) * 0.25).to(runner.dtype)
     layers = runner.layers
+    residual = (torch.randn((batch, K), device=runner.device) * 0.25).to(runner.dtype)
+    fused = runner.quant != "none" and batch <= 4
+
+    def launch(L):   # the gate_up launch of a decode step, as LlamaRunner._layer issues it
+        if not fused:
+            return L["gate_up"](x)
+        if L["gate_up"].w.pair_halves:
+            return ops.w4a16_gate_up_silu(x, residual, L["ln2"], runner.cfg.rms_eps, L["gate_up"].w)
+        return ops.w4a16_gemm_add_rms_norm(x, residual, L["ln2"], runner.cfg.rms_eps, L["gate_up"].w)
+
     for L in layers[:4]:
-        L["gate_up"](x)
+        launch(L)
     torch.cuda.synchronize()
     times = []
     for _ in range(reps):
@@ -63,13 +73,17 @@ def time_dominant_kernel(runner, batch, reps=6):
         for L in layers:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            L["gate_up"](x)
+            launch(L)
             b.record()
             evs.append((a, b))
         torch.cuda.synchronize()
         times += [a.elapsed_time(b) * 1e-3 for a, b in evs]
     avg = sum(times) / len(times)
     nbytes = w4a16_bytes(batch, K, N, runner.G, runner.quant == "awq")
+    if fused:   # + residual in/out and norm weight of the prologue; the SiLU epilogue writes N/2 per row
+        nbytes += 3 * batch * K * 2 + K * 2
+        if layers[0]["gate_up"].w.pair_halves:
+            nbytes -= batch * (N // 2) * 2
     return {"bound": "hbm", "achieved": nbytes / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": nbytes / avg / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "kernel": "w4a16_burst_kernel (gate_up_proj %dx%d + add/RMSNorm prologue + SiLU epilogue, M=%d)" % (K, N, batch),

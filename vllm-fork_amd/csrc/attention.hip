@@ -45,6 +45,7 @@ struct PAParams {
   // token's k/v sit k_off / v_off elements after the row start; NeoX RoPE over the whole head
   const int64_t* positions;
   const uint16_t* cos_sin;  // [max_pos, HEAD] in the activation dtype
+  unsigned long long* stamps;  // diagnostics: 10 timestamps per workgroup (8 at 100 MHz, 2 shader-clock), or null
   int k_off, v_off;
 };
 
@@ -73,16 +74,27 @@ __device__ inline void rope8(u32x4& x, u32x4& y, const u32x4 c, const u32x4 s) {
   }
 }
 
+#define PA_STAMP(i)                                                                              \
+  if (p.stamps && threadIdx.x == 0)                                                              \
+    p.stamps[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * 10 + (i)] = ((i) >= 8 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime())
+
+static unsigned long long* g_pa_stamps = nullptr;
+
 template <typename DT, int HEAD, bool KVFP8, bool FUSED>
 __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) {
   __shared__ float s_max[4][16];
   __shared__ float s_sum[4][16];
   __shared__ __attribute__((aligned(16))) float s_out[4][16][HEAD];
+  // fused decode step: the new token's rotated key and its value, as the cache will hold them
+  __shared__ __attribute__((aligned(16))) uint16_t s_knew[FUSED ? HEAD : 8];
+  __shared__ __attribute__((aligned(16))) uint16_t s_vnew[FUSED ? HEAD : 8];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kq = lane >> 4, col = lane & 15;
   const int g = p.num_heads / p.num_kv_heads;
   const int gp = p.gp, QB = 16 / gp;
+  PA_STAMP(0);
+  PA_STAMP(8);
 
   int seq, q0, qlen, qstart;
   if (p.varlen) {
@@ -101,12 +113,35 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
       if (p.qsl[seq + 1] - qstart != 1) return;  // prompt rows are not handled here
     }
   }
+  // Plain decode rows: the block-table entries and the query fragments depend on the block index
+  // only, so they are requested before the sequence length is known (one round trip saved).
+  constexpr int DS = HEAD / 32;
+  const bool plain = !p.varlen && !p.qsl;
+  int phys_pre[4] = {0, 0, 0, 0};
+  u32x4 qf[DS];
+  if (plain) {
+    const int32_t* tb = p.block_tables + (size_t)seq * p.max_blocks;
+#pragma unroll
+    for (int T = 0; T < 4; T++) {
+      const int t0 = blockIdx.y * MI355Q_PA_PARTITION + wave * 64 + T * 16;
+      phys_pre[T] = tb[min(t0 / p.bs, p.max_blocks - 1)];
+    }
+    const int hd = blockIdx.z * g + min((col % gp), g - 1);
+    const uint16_t* qp0 = p.q + (size_t)seq * p.q_stride + (size_t)hd * HEAD;
+#pragma unroll
+    for (int ds = 0; ds < DS; ds++) {
+      const int d0 = KVFP8 ? 16 * (4 * (ds >> 1) + kq) + 8 * (ds & 1) : 32 * ds + 8 * kq;
+      qf[ds] = *reinterpret_cast<const u32x4*>(qp0 + d0);
+    }
+  }
+  const int64_t pos = FUSED ? p.positions[seq] : 0;
   const int seq_len = p.seq_lens[seq];
   const int q_in_blk = min(QB, qlen - q0);
   const int blk_ctx = seq_len - qlen + q0 + q_in_blk;  // tokens visible to the last column
   const int part = blockIdx.y;
   const int p0 = part * MI355Q_PA_PARTITION;
   if (p0 >= blk_ctx) return;
+  PA_STAMP(6);
   const int kvh = blockIdx.z;
 
   // this lane's query column
@@ -124,63 +159,40 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
   // ---- Q fragments (B operand): column = this lane's query column --------------------
   // 16-bit cache: k index of step ds is d = 32 ds + 8 kq + j
   // fp8 cache   : one 16-byte K load covers d = 16 (4 (ds/2) + kq) + 8 (ds&1) + j
-  constexpr int DS = HEAD / 32;
-  u32x4 qf[DS];
-  const uint16_t* qp = p.q + (size_t)qrow * p.q_stride + (size_t)head * HEAD;
+  if (!plain) {
+    const uint16_t* qp = p.q + (size_t)qrow * p.q_stride + (size_t)head * HEAD;
 #pragma unroll
-  for (int ds = 0; ds < DS; ds++) {
-    const int d0 = KVFP8 ? 16 * (4 * (ds >> 1) + kq) + 8 * (ds & 1) : 32 * ds + 8 * kq;
-    qf[ds] = *reinterpret_cast<const u32x4*>(qp + d0);
+    for (int ds = 0; ds < DS; ds++) {
+      const int d0 = KVFP8 ? 16 * (4 * (ds >> 1) + kq) + 8 * (ds & 1) : 32 * ds + 8 * kq;
+      qf[ds] = *reinterpret_cast<const u32x4*>(qp + d0);
+    }
   }
 
+  // Fused decode step: everything the new token needs is requested here, together with the
+  // cache reads below, so that one memory round trip serves the whole kernel; its arithmetic
+  // (RoPE, cache write, patching the new token into the K/V fragments) follows the requests.
+  u32x4 cfrag[FUSED ? DS / 2 : 1], sfrag[FUSED ? DS / 2 : 1];
+  const int tnew = seq_len - 1;
+  const bool owns_new = FUSED && part == tnew / MI355Q_PA_PARTITION;
+  uint16_t nk_x = 0, nk_y = 0, nk_c = 0, nk_s = 0, nv = 0;
   if constexpr (FUSED) {
-    // RoPE on the query fragments: the partner d + HEAD/2 of every element sits in fragment
-    // ds + DS/2 of the same lane
-    const int64_t pos = p.positions[seq];
     const uint16_t* cs = p.cos_sin + (size_t)pos * HEAD;
 #pragma unroll
     for (int ds = 0; ds < DS / 2; ds++) {
       const int d0 = KVFP8 ? 16 * (4 * (ds >> 1) + kq) + 8 * (ds & 1) : 32 * ds + 8 * kq;
-      const u32x4 c = *reinterpret_cast<const u32x4*>(cs + d0);
-      const u32x4 s = *reinterpret_cast<const u32x4*>(cs + HEAD / 2 + d0);
-      rope8<DT>(qf[ds], qf[ds + DS / 2], c, s);
+      cfrag[ds] = *reinterpret_cast<const u32x4*>(cs + d0);
+      sfrag[ds] = *reinterpret_cast<const u32x4*>(cs + HEAD / 2 + d0);
     }
-    // The workgroup whose partition holds the newest position rotates the new key and writes
-    // the new key/value into the cache before anyone reads that slot.
-    const int tnew = seq_len - 1;
-    if (part == tnew / MI355Q_PA_PARTITION) {
+    if (owns_new) {
       const uint16_t* rowp = p.q + (size_t)qstart * p.q_stride;
-      const int blk = table[tnew / p.bs], off = tnew % p.bs;
-      constexpr int X = KVFP8 ? 16 : 8;
-      const size_t base = (size_t)blk * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
       const int t = threadIdx.x;
       if (t < HEAD / 2) {
         const uint16_t* kp = rowp + p.k_off + kvh * HEAD;
-        const float x = DT::to_f32(kp[t]), y = DT::to_f32(kp[t + HEAD / 2]);
-        const float c = DT::to_f32(cs[t]), s = DT::to_f32(cs[HEAD / 2 + t]);
-        const uint16_t xr = DT::from_f32(x * c - y * s), yr = DT::from_f32(y * c + x * s);
-        const int d1 = t, d2 = t + HEAD / 2;
-        const size_t i1 = base + ((size_t)(d1 / X) * p.bs + off) * X + d1 % X;
-        const size_t i2 = base + ((size_t)(d2 / X) * p.bs + off) * X + d2 % X;
-        if constexpr (KVFP8) {
-          const float ks = *p.k_scale;
-          reinterpret_cast<uint8_t*>(const_cast<void*>(p.kc))[i1] = f32_to_fp8(DT::to_f32(xr) / ks);
-          reinterpret_cast<uint8_t*>(const_cast<void*>(p.kc))[i2] = f32_to_fp8(DT::to_f32(yr) / ks);
-        } else {
-          reinterpret_cast<uint16_t*>(const_cast<void*>(p.kc))[i1] = xr;
-          reinterpret_cast<uint16_t*>(const_cast<void*>(p.kc))[i2] = yr;
-        }
+        nk_x = kp[t]; nk_y = kp[t + HEAD / 2];
+        nk_c = cs[t]; nk_s = cs[HEAD / 2 + t];
       } else if (t >= 128 && t < 128 + HEAD) {
-        const int d = t - 128;
-        const uint16_t vb = rowp[p.v_off + kvh * HEAD + d];
-        const size_t vi = base + (size_t)d * p.bs + off;
-        if constexpr (KVFP8)
-          reinterpret_cast<uint8_t*>(const_cast<void*>(p.vc))[vi] = f32_to_fp8(DT::to_f32(vb) / *p.v_scale);
-        else
-          reinterpret_cast<uint16_t*>(const_cast<void*>(p.vc))[vi] = vb;
+        nv = rowp[p.v_off + kvh * HEAD + (t - 128)];
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
     }
   }
 
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
 #pragma unroll
   for (int T = 0; T < 4; T++) {
     const int t0 = wave_t0 + T * 16;
-    phys[T] = t0 < blk_ctx ? table[t0 / p.bs] : -1;
+    phys[T] = t0 < blk_ctx ? (plain ? phys_pre[T] : table[t0 / p.bs]) : -1;
   }
 #pragma unroll
   for (int T = 0; T < 4; T++) {
@@ -239,6 +251,91 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
     }
   }
 
+  if constexpr (FUSED) {
+    // RoPE on the query fragments: the partner d + HEAD/2 of every element sits in fragment
+    // ds + DS/2 of the same lane
+#pragma unroll
+    for (int ds = 0; ds < DS / 2; ds++) rope8<DT>(qf[ds], qf[ds + DS / 2], cfrag[ds], sfrag[ds]);
+    PA_STAMP(7);
+    // The workgroup whose partition holds the newest position rotates the new key, sends key and
+    // value to the cache (nobody waits for those stores: this step's reads of that slot are
+    // replaced below) and shares them through LDS in the form the cache holds them.
+    if (owns_new) {
+      const int blk = table[tnew / p.bs], off = tnew % p.bs;
+      constexpr int X = KVFP8 ? 16 : 8;
+      const size_t base = (size_t)blk * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+      const int t = threadIdx.x;
+      if (t < HEAD / 2) {
+        const float x = DT::to_f32(nk_x), y = DT::to_f32(nk_y);
+        const float c = DT::to_f32(nk_c), sn = DT::to_f32(nk_s);
+        const uint16_t xr = DT::from_f32(x * c - y * sn), yr = DT::from_f32(y * c + x * sn);
+        const int d1 = t, d2 = t + HEAD / 2;
+        const size_t i1 = base + ((size_t)(d1 / X) * p.bs + off) * X + d1 % X;
+        const size_t i2 = base + ((size_t)(d2 / X) * p.bs + off) * X + d2 % X;
+        if constexpr (KVFP8) {
+          const float ks = *p.k_scale;
+          const uint8_t b1 = f32_to_fp8(DT::to_f32(xr) / ks), b2 = f32_to_fp8(DT::to_f32(yr) / ks);
+          reinterpret_cast<uint8_t*>(const_cast<void*>(p.kc))[i1] = b1;
+          reinterpret_cast<uint8_t*>(const_cast<void*>(p.kc))[i2] = b2;
+          reinterpret_cast<uint8_t*>(s_knew)[d1] = b1;
+          reinterpret_cast<uint8_t*>(s_knew)[d2] = b2;
+        } else {
+          reinterpret_cast<uint16_t*>(const_cast<void*>(p.kc))[i1] = xr;
+          reinterpret_cast<uint16_t*>(const_cast<void*>(p.kc))[i2] = yr;
+          s_knew[d1] = xr;
+          s_knew[d2] = yr;
+        }
+      } else if (t >= 128 && t < 128 + HEAD) {
+        const int d = t - 128;
+        const size_t vi = base + (size_t)d * p.bs + off;
+        if constexpr (KVFP8) {
+          const uint8_t b = f32_to_fp8(DT::to_f32(nv) / *p.v_scale);
+          reinterpret_cast<uint8_t*>(const_cast<void*>(p.vc))[vi] = b;
+          reinterpret_cast<uint8_t*>(s_vnew)[d] = b;
+        } else {
+          reinterpret_cast<uint16_t*>(const_cast<void*>(p.vc))[vi] = nv;
+          s_vnew[d] = nv;
+        }
+      }
+      __syncthreads();
+      // patch the fragments of the tile that holds the new position (it belongs to one wave)
+      const int tl = tnew - wave_t0;
+      if (tl >= 0 && tl < 64) {
+#pragma unroll
+        for (int T = 0; T < 4; T++) {
+          if ((tl >> 4) == T) {
+            if (col == (tl & 15)) {
+              if constexpr (!KVFP8) {
+#pragma unroll
+                for (int ds = 0; ds < DS; ds++) kreg[T][ds] = *reinterpret_cast<const u32x4*>(s_knew + 32 * ds + 8 * kq);
+              } else {
+#pragma unroll
+                for (int sp = 0; sp < DS / 2; sp++)
+                  kreg[T][sp] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(s_knew) + 16 * (sp * 4 + kq));
+              }
+            }
+            if (kq == ((tl & 15) >> 2)) {
+              const int j = tl & 3;
+#pragma unroll
+              for (int dt = 0; dt < DTILES; dt++) {
+                if constexpr (!KVFP8) {
+                  const uint32_t val = s_vnew[dt * 16 + col];
+                  const uint32_t old = (j >> 1) ? vreg[T][dt][1] : vreg[T][dt][0];
+                  const uint32_t upd = (j & 1) ? ((old & 0x0000ffffu) | (val << 16)) : ((old & 0xffff0000u) | val);
+                  if (j >> 1) vreg[T][dt][1] = upd; else vreg[T][dt][0] = upd;
+                } else {
+                  const uint32_t val = reinterpret_cast<const uint8_t*>(s_vnew)[dt * 16 + col];
+                  vreg[T][dt][0] = (vreg[T][dt][0] & ~(0xffu << (8 * j))) | (val << (8 * j));
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  PA_STAMP(1);
   // ---- S^T = K Q^T ---------------------------------------------------------------------------
   f32x4 st[4];
 #pragma unroll
@@ -261,8 +358,11 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
     }
   }
 
+  PA_STAMP(2);
   // ---- logits, partition max / sum per column ------------------------------------------
-  float mx = -INFINITY;
+  // Each wave normalises against its own maximum; one exchange of (max, sum) per wave through
+  // LDS then gives the partition maximum, the rescaling factor of this wave and the total.
+  float mw = -INFINITY;
 #pragma unroll
   for (int T = 0; T < 4; T++)
 #pragma unroll
@@ -271,30 +371,39 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
       float v = st[T][r] * scale + slope * (float)(tok - ctx_c + 1);
       v = tok < ctx_c ? v : -INFINITY;
       st[T][r] = v;
-      mx = fmaxf(mx, v);
+      mw = fmaxf(mw, v);
     }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  if (kq == 0) s_max[wave][col] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(s_max[0][col], s_max[1][col]), fmaxf(s_max[2][col], s_max[3][col]));
-  const float mref = mx == -INFINITY ? 0.f : mx;
-  float sum = 0.f;
+  mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
+  mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+  const float mwref = mw == -INFINITY ? 0.f : mw;
+  float sw = 0.f;
 #pragma unroll
   for (int T = 0; T < 4; T++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const float e = __expf(st[T][r] - mref);
+      const float e = __expf(st[T][r] - mwref);
       st[T][r] = e;
-      sum += e;
+      sw += e;
     }
-  sum += __shfl_xor(sum, 16, 64);
-  sum += __shfl_xor(sum, 32, 64);
-  if (kq == 0) s_sum[wave][col] = sum;
+  sw += __shfl_xor(sw, 16, 64);
+  sw += __shfl_xor(sw, 32, 64);
+  if (kq == 0) {
+    s_max[wave][col] = mw;
+    s_sum[wave][col] = sw;
+  }
   __syncthreads();
-  sum = (s_sum[0][col] + s_sum[1][col]) + (s_sum[2][col] + s_sum[3][col]);
-  const float inv = 1.0f / (sum + 1e-6f);
+  float mx = fmaxf(fmaxf(s_max[0][col], s_max[1][col]), fmaxf(s_max[2][col], s_max[3][col]));
+  const float mref = mx == -INFINITY ? 0.f : mx;
+  float sum = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < 4; w2++) {
+    const float m2 = s_max[w2][col];
+    sum += m2 == -INFINITY ? 0.f : s_sum[w2][col] * __expf(m2 - mref);
+  }
+  // this wave's probabilities relative to the partition maximum, normalised
+  const float inv = (mw == -INFINITY ? 0.f : __expf(mwref - mref)) / (sum + 1e-6f);
 
+  PA_STAMP(3);
   // ---- O^T += V^T P^T ---------------------------------------------------------------------
   f32x4 o[DTILES];
 #pragma unroll
@@ -333,6 +442,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
     }
   }
 
+  PA_STAMP(4);
   // ---- cross-wave sum of O, store ---------------------------------------------------------
   const float vs = KVFP8 ? *p.v_scale : 1.0f;
 #pragma unroll
@@ -341,19 +451,27 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
   __syncthreads();
 
   const bool single = p.max_parts == 1;
-  for (int idx = threadIdx.x; idx < 16 * HEAD; idx += 256) {
-    const int c = idx / HEAD, d = idx - c * HEAD;
+  for (int idx = threadIdx.x; idx < 16 * HEAD / 8; idx += 256) {   // 8 consecutive head dims per thread
+    const int c = idx / (HEAD / 8), d = (idx - c * (HEAD / 8)) * 8;
     const int cqi = c / gp, chi = c % gp;
     if (chi >= g || cqi >= q_in_blk) continue;
-    const float v = (s_out[0][c][d] + s_out[1][c][d]) + (s_out[2][c][d] + s_out[3][c][d]);
+    f32x4 lo4 = f32x4{0.f, 0.f, 0.f, 0.f}, hi4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w2 = 0; w2 < 4; w2++) {
+      lo4 += *reinterpret_cast<const f32x4*>(&s_out[w2][c][d]);
+      hi4 += *reinterpret_cast<const f32x4*>(&s_out[w2][c][d + 4]);
+    }
+    u32x4 o8;
+    o8[0] = pack2<DT>(lo4[0], lo4[1]); o8[1] = pack2<DT>(lo4[2], lo4[3]);
+    o8[2] = pack2<DT>(hi4[0], hi4[1]); o8[3] = pack2<DT>(hi4[2], hi4[3]);
     const size_t row = (size_t)(qstart + q0 + cqi);
     const int h = kvh * g + chi;
-    if (single)
-      reinterpret_cast<uint16_t*>(p.out)[(row * p.num_heads + h) * HEAD + d] = DT::from_f32(v);
-    else
-      reinterpret_cast<uint16_t*>(p.tmp_out)[((row * p.num_heads + h) * p.max_parts + part) * HEAD + d] =
-          DT::from_f32(v);
+    uint16_t* dst = single ? reinterpret_cast<uint16_t*>(p.out) + (row * p.num_heads + h) * HEAD + d
+                           : reinterpret_cast<uint16_t*>(p.tmp_out) + ((row * p.num_heads + h) * p.max_parts + part) * HEAD + d;
+    *reinterpret_cast<u32x4*>(dst) = o8;
   }
+  PA_STAMP(5);
+  PA_STAMP(9);
   if (!single && wave == 0 && kq == 0 && col_valid) {
     const size_t row = (size_t)(qstart + q0 + qi);
     const size_t o2 = (row * p.num_heads + (kvh * g + hi)) * p.max_parts + part;
@@ -425,6 +543,7 @@ static int launch_pa(const PAParams& p, int head_size, int kv_fp8, int qblocks, 
 
 static int pa_common(PAParams& p, int head_size, int block_size, int max_seq_len, int dtype,
                      int kv_fp8, const char* what) {
+  p.stamps = g_pa_stamps;
   MI355Q_REQUIRE(dtype == MI355Q_BF16 || dtype == MI355Q_FP16, "%s: dtype must be bf16 or fp16", what);
   MI355Q_REQUIRE(head_size == 64 || head_size == 128, "%s: head_size %d not in {64,128}", what, head_size);
   MI355Q_REQUIRE(block_size > 0 && block_size % 16 == 0, "%s: block_size %d must be a multiple of 16", what, block_size);
@@ -525,3 +644,6 @@ extern "C" int mi355q_decode_attention_fused(
   if (dtype == MI355Q_BF16) return launch_pa<BF16>(p, head_size, kv_fp8, num_seqs, 1, (hipStream_t)stream, true);
   return launch_pa<FP16>(p, head_size, kv_fp8, num_seqs, 1, (hipStream_t)stream, true);
 }
+
+/* Diagnostics (not part of the public ABI): per-workgroup 100 MHz timestamps of the attention kernel. */
+extern "C" void mi355q_debug_attention_stamps(void* stamps) { g_pa_stamps = (unsigned long long*)stamps; }
