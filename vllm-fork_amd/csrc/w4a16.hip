@@ -1282,15 +1282,23 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
 }
 
 // ---- dequantize ---------------------------------------------------------------
+// One workgroup dequantises a [32 k x 64 n] tile: each thread expands one packed dword (8 k
+// of one channel) into LDS, then the tile leaves as 32 rows of 128 contiguous bytes.
 template <typename DT>
-__global__ void dequantize_kernel(const uint32_t* __restrict__ wp, const uint16_t* __restrict__ scales,
-                                  const uint16_t* __restrict__ zc, uint16_t* __restrict__ W, int K,
-                                  int N, int G, int sw) {
-  const size_t nd = (size_t)K * N / 8;
-  for (size_t d = blockIdx.x * (size_t)blockDim.x + threadIdx.x; d < nd;
-       d += (size_t)gridDim.x * blockDim.x) {
-    int k0, n;
-    dword_pos(K, sw, d, &k0, &n);
+__global__ __launch_bounds__(256) void dequantize_kernel(const uint32_t* __restrict__ wp,
+                                                         const uint16_t* __restrict__ scales,
+                                                         const uint16_t* __restrict__ zc,
+                                                         uint16_t* __restrict__ W, int K, int N, int G,
+                                                         int sw) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[32][64 + 8];
+  const int nb = blockIdx.x * 64, kb = blockIdx.y * 32;
+  const int t = threadIdx.x;
+  {
+    const int kq = t >> 6, nl = t & 63;
+    const int n = nb + nl, k0 = kb + 8 * kq;
+    size_t d;
+    int sh;
+    packed_pos(K, sw, k0, n, &d, &sh);
     const int g = k0 / G;
     const float s = DT::to_f32(scales[(size_t)g * N + n]);
     const float z = zc ? DT::to_f32(zc[(size_t)g * N + n]) - DT::int4_bias : 8.0f;
@@ -1298,9 +1306,12 @@ __global__ void dequantize_kernel(const uint32_t* __restrict__ wp, const uint16_
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const float q = (float)((w >> nibble_shift(j)) & 0xfu);
-      W[(size_t)(k0 + j) * N + n] = DT::from_f32((q - z) * s);
+      tile[8 * kq + j][nl] = DT::from_f32((q - z) * s);
     }
   }
+  __syncthreads();
+  const int row = t >> 3, v = t & 7;
+  *reinterpret_cast<u32x4*>(W + (size_t)(kb + row) * N + nb + 8 * v) = *reinterpret_cast<const u32x4*>(&tile[row][8 * v]);
 }
 
 }  // namespace mi355q
@@ -1357,8 +1368,8 @@ extern "C" int mi355q_w4a16_dequantize(const void* packed, const void* scales, c
   if (int e = check_tile(tile, K, G, N)) return e;
   MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w4a16_dequantize: act_dtype must be bf16 or fp16");
   MI355Q_REQUIRE(packed && scales && w, "w4a16_dequantize: null pointer");
-  const size_t nd = (size_t)K * N / 8;
-  const int grid = (int)((nd + 255) / 256 < 8192 ? (nd + 255) / 256 : 8192);
+  MI355Q_REQUIRE(((uintptr_t)w & 15) == 0, "w4a16_dequantize: output must be 16-byte aligned");
+  const dim3 grid(N / 64, K / 32);
   if (act_dtype == MI355Q_BF16)
     hipLaunchKernelGGL((dequantize_kernel<BF16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const uint32_t*)packed, (const uint16_t*)scales, (const uint16_t*)zc,
