@@ -702,7 +702,7 @@ constexpr int BURST_XV = 2;  // 16-byte activation vectors a thread may hold in 
 
 template <typename DT, int NS, int CPW, bool HAS_ZC, int PRO>
 __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel(const BurstParams p) {
-  constexpr int SW = 16 * NS, NE = 4 * NS, QW = 4 * NS;
+  constexpr int SW = 16 * NS, QW = 4 * NS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nw = p.nw, nthreads = nw * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -713,8 +713,8 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
   const int groups = p.chunks / p.gchunks;
   const int astride = p.K + 8;  // +16 B per row: rows land on different LDS banks
 
-  float* red = reinterpret_cast<float*>(smem);                                 // [nw][NE][64]
-  uint16_t* sc_l = reinterpret_cast<uint16_t*>(smem + (size_t)nw * NE * 256);  // [groups][SW]
+  float* red = reinterpret_cast<float*>(smem);                                 // [nw][rows_pp][SW]
+  uint16_t* sc_l = reinterpret_cast<uint16_t*>(smem + (size_t)nw * p.rows_pp * SW * 4);  // [groups][SW]
   uint16_t* zc_l = sc_l + (size_t)groups * SW;                                 // [groups][SW] (HAS_ZC)
   uint16_t* act = zc_l + (HAS_ZC ? (size_t)groups * SW : 0);                   // [rows_pp][astride]
 
@@ -979,24 +979,21 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
     }
   }
 
-  // ---- cross-wave reduction through LDS, then every (row, 4 channels) item is finished by one thread
+  // ---- cross-wave reduction through LDS: lanes of real rows publish their 4 NS sums (channels
+  // QW kq + 4 sub + r) as float4s; every (row, 4 channels) item is then finished by one thread
+  if (ml < Mt) {
+    float* mine = red + ((size_t)wave * p.rows_pp + ml) * SW + QW * kq;
 #pragma unroll
-  for (int sub = 0; sub < NS; sub++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) red[(wave * NE + 4 * sub + r) * 64 + lane] = tot[sub][r];
+    for (int sub = 0; sub < NS; sub++) *reinterpret_cast<f32x4*>(mine + 4 * sub) = tot[sub];
+  }
   __syncthreads();
   if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
   for (int it = threadIdx.x; it < Mt * QW; it += nthreads) {
     const int m_l = it / QW, nq = it % QW;
     const int nl = 4 * nq;
-    const int src_lane = 16 * (nl / QW) + m_l, e0 = nl % QW;
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float s = 0.f;
-      for (int i = 0; i < nw; i++) s += red[(i * NE + e0 + j) * 64 + src_lane];
-      v[j] = s;
-    }
+    f32x4 acc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < nw; i++) acc4 += *reinterpret_cast<const f32x4*>(red + ((size_t)i * p.rows_pp + m_l) * SW + nl);
+    float v[4] = {acc4[0], acc4[1], acc4[2], acc4[3]};
     const int n = strip * SW + nl;
     if (p.bias) {  // bias is added to the rounded GEMM result, as output.add_(bias) does
       const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
@@ -1055,8 +1052,9 @@ static BurstPlan plan_burst(int M, int K, int G, int ns, bool has_zc) {
     }
   }
   if (!bp.ok) return bp;
-  const size_t fixed = (size_t)bp.nw * ns * 4 * 256 + (size_t)groups * ns * 16 * 2 * (has_zc ? 2 : 1);
-  const size_t row = (size_t)(K + 8) * 2;
+  // LDS: reduction scratch [nw][rows][SW] fp32, strip scales (and zero points), staged rows
+  const size_t fixed = (size_t)groups * ns * 16 * 2 * (has_zc ? 2 : 1);
+  const size_t row = (size_t)(K + 8) * 2 + (size_t)bp.nw * ns * 16 * 4;
   if (fixed + row > 160 * 1024) { bp.ok = false; return bp; }
   bp.rows_pp = (int)std::min<size_t>(16, (160 * 1024 - fixed) / row);
   bp.rows_pp = std::min(bp.rows_pp, M);
