@@ -89,8 +89,8 @@ int mi355q_w4a16_choose_strip(int K, int N, int G);
  *   qweight : device, layout per src_layout
  *   qzeros  : device or NULL (required unless zp_mode == MI355Q_ZP_CONST)
  *   packed  : device out, K*N/2 bytes
- *   zc      : device out, (K/G)*N 16-bit values of (bias + z) in act_dtype, or
- *             NULL when zp_mode == MI355Q_ZP_CONST
+ *   zc      : device out, (K/G)*N 16-bit values of (bias + z) in act_dtype, strip-major like the
+ *             scales (see mi355q_w4a16_gemm), or NULL when zp_mode == MI355Q_ZP_CONST
  * Requires K % 32 == 0, N % 64 == 0, G % 32 == 0 and K % G == 0 (G <= 0 means K).
  */
 int mi355q_w4a16_repack(const int32_t* qweight, const int32_t* qzeros, void* packed, void* zc,
@@ -123,7 +123,9 @@ int mi355q_workspace_init(void* workspace, size_t workspace_bytes, mi355q_stream
  * (mixed_precision/triton_w4a16.py:164-270).
  *   a      : [M, K] act_dtype, row stride lda elements (lda % 8 == 0)
  *   packed : output of mi355q_w4a16_repack
- *   scales : [K/G, N] act_dtype (checkpoint layout, not repacked)
+ *   scales : act_dtype, strip-major [N/tile][K/G][tile]: element (g, n) of the checkpoint's
+ *            [K/G, N] tensor at ((n / tile) * (K/G) + g) * tile + n % tile, so that one
+ *            workgroup's scales are one contiguous run (zc from the repack uses the same order)
  *   zc     : from the repack, or NULL for symmetric uint4b8
  *   bias   : [N] act_dtype or NULL
  *   c      : [M, N] act_dtype, contiguous

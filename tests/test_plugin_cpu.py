@@ -299,7 +299,9 @@ def test_awq_tp_sharding_and_repack(tp):
         assert np.array_equal(_unpacked(col), q[:, rank * h:(rank + 1) * h])
         assert np.array_equal(_unpacked(row), q[rank * (K // 2):(rank + 1) * (K // 2)])
         # zc = 1024 + z in fp16 (the magic-number bias of the fp16 kernel plus the zero point)
-        zc = orc.h16_to_f32(col.w_zc.data.view(torch.int16).numpy().view(np.uint16), orc.FP16)
+        from mi355q import ops
+        zc_rm = ops.scales_row_major(col.mi355q_weight, zc=True).contiguous()
+        zc = orc.h16_to_f32(zc_rm.view(torch.int16).numpy().view(np.uint16), orc.FP16)
         assert np.array_equal(zc, 1024.0 + z[:, rank * h:(rank + 1) * h])
 
 

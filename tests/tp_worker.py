@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "vllm-fork_amd")]
 
 import oracle as orc  # noqa: E402
-from mi355q import _lib  # noqa: E402
+from mi355q import _lib, ops  # noqa: E402
 from mi355q.plugin import AutoGPTQConfig, MI355XW4A16LinearKernel, parallel  # noqa: E402
 from mi355q.plugin.linear import (ColumnParallelLinear, MergedColumnParallelLinear,  # noqa: E402
                                   RowParallelLinear)
@@ -35,7 +35,7 @@ def oracle_apply(self, layer, x, bias=None):
     w = layer.mi355q_weight
     q = np.empty((w.K, w.N), dtype=np.int32)
     _lib.check(_lib.lib().mi355q_w4a16_unpack_host(w.packed.data_ptr(), q.ctypes.data, w.K, w.N, w.tile))
-    out = orc.w4a16_gemm(bits(x.reshape(-1, w.K)), orc.gptq_pack(q), bits(w.scales), None,
+    out = orc.w4a16_gemm(bits(x.reshape(-1, w.K)), orc.gptq_pack(q), bits(ops.scales_row_major(w)), None,
                          None if bias is None else bits(bias), G=w.G)
     return bf(out).reshape(x.shape[:-1] + (w.N,))
 

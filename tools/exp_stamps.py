@@ -23,7 +23,7 @@ def run(name, K, N, pro):
         else: ops.w4a16_gemm(x, w)
     for w in ws: call(w)
     blocks = N // ws[0].tile
-    st = torch.zeros((blocks, 4), dtype=torch.int64, device=dev)
+    st = torch.zeros((blocks, 8), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     L.mi355q_debug_burst_stamps(st.data_ptr())
     call(ws[3])      # cold weights
@@ -33,7 +33,7 @@ def run(name, K, N, pro):
     t0 = t[:, 0].min()
     t = (t - t0) / 100.0   # us
     q = lambda v: f"{v.min():5.2f}/{v.median():5.2f}/{v.max():5.2f}"
-    print(f"{name:10s} tile {ws[0].tile:3d} blocks {blocks}: start {q(t[:,0])} | staged {q(t[:,1])} | consumed {q(t[:,2])} | done {q(t[:,3])}  (us after first start, min/med/max)")
+    print(f"{name:10s} tile {ws[0].tile:3d} blocks {blocks}: start {q(t[:,0])} | scales in LDS (thread 0) {q(t[:,4])} | x staged (thread 0) {q(t[:,5])} | staged {q(t[:,1])} | consumed {q(t[:,2])} | done {q(t[:,3])}  (us after first start, min/med/max)")
 for name, K, N, pro in [("gate_up", 4096, 28672, "norm"), ("gate_up_n", 4096, 28672, "none"), ("down", 14336, 4096, "silu"),
                         ("down_n", 14336, 4096, "none"), ("qkv", 4096, 6144, "norm"), ("o", 4096, 4096, "none")]:
     run(name, K, N, pro)

@@ -124,6 +124,12 @@ __host__ __device__ static inline uint32_t repack_dword(const int32_t* qw, int l
   return w;
 }
 
+// Scales and zero points are stored strip-major, [N / sw][K / G][sw]: everything one workgroup
+// needs is one contiguous run.
+__host__ __device__ static inline size_t scale_idx(int g, int n, int groups, int sw) {
+  return ((size_t)(n / sw) * groups + g) * sw + n % sw;
+}
+
 __host__ __device__ static inline uint16_t repack_zc(const int32_t* qz, int zp_mode, int N, int g,
                                                      int n, int act_dtype, int layout) {
   n = pair_src(n, N, layout);
@@ -142,11 +148,12 @@ __global__ void repack_weight_kernel(const int32_t* __restrict__ qw, uint32_t* _
 }
 
 __global__ void repack_zc_kernel(const int32_t* __restrict__ qz, uint16_t* __restrict__ zc, int N,
-                                 int groups, int zp_mode, int act_dtype, int layout) {
+                                 int groups, int zp_mode, int act_dtype, int layout, int sw) {
   const size_t total = (size_t)groups * N;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
        e += (size_t)gridDim.x * blockDim.x)
-    zc[e] = repack_zc(qz, zp_mode, N, (int)(e / N), (int)(e % N), act_dtype, layout);
+    zc[scale_idx((int)(e / N), (int)(e % N), groups, sw)] =
+        repack_zc(qz, zp_mode, N, (int)(e / N), (int)(e % N), act_dtype, layout);
 }
 
 static inline int chunk_steps(int G) { return (G % 128 == 0) ? 4 : (G % 64 == 0) ? 2 : 1; }
@@ -221,7 +228,7 @@ extern "C" int mi355q_w4a16_repack(const int32_t* qweight, const int32_t* qzeros
     const size_t nz = (size_t)(K / G) * N;
     const int gz = (int)((nz + 255) / 256 < 4096 ? (nz + 255) / 256 : 4096);
     hipLaunchKernelGGL(repack_zc_kernel, dim3(gz), dim3(256), 0, (hipStream_t)stream, qzeros,
-                       (uint16_t*)zc, N, K / G, zp_mode, act_dtype, src_layout);
+                       (uint16_t*)zc, N, K / G, zp_mode, act_dtype, src_layout, tile);
     if (int e = check_launch("repack_zc_kernel")) return e;
   }
   return MI355Q_OK;
@@ -240,7 +247,8 @@ extern "C" int mi355q_w4a16_repack_host(const int32_t* qweight, const int32_t* q
   if (zp_mode != MI355Q_ZP_CONST) {
     uint16_t* z = (uint16_t*)zc;
     for (int g = 0; g < K / G; g++)
-      for (int n = 0; n < N; n++) z[(size_t)g * N + n] = repack_zc(qzeros, zp_mode, N, g, n, act_dtype, src_layout);
+      for (int n = 0; n < N; n++)
+        z[scale_idx(g, n, K / G, tile)] = repack_zc(qzeros, zp_mode, N, g, n, act_dtype, src_layout);
   }
   return MI355Q_OK;
 }
@@ -385,7 +393,8 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
   const int kbase = c0 * CS * 32;  // first k of this block's range
   const int krange = (c1 - c0) * CS * 32;
   const uint16_t* arow = act + (size_t)min(ml, Mt - 1) * krange + 8 * kq;
-  const size_t sc_off = (size_t)strip * SW + (SW / 4) * kq;
+  const int groups = p.K / p.G;
+  const size_t sc_off = (size_t)strip * groups * SW + (SW / 4) * kq;  // + g * SW: strip-major scales
 
   u32x4 w[PF][CT], b[2][CS];  // activations: one chunk ahead
   Dwords<ND> sc[PF];
@@ -394,7 +403,7 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
 #pragma unroll
     for (int t = 0; t < CT; t++) w[slot][t] = __builtin_nontemporal_load(wstrip + (size_t)(c * CT + t) * 64);
     const int g = (c * CS * 32) / p.G;
-    sc[slot] = load_dwords<ND>(sc_e + (size_t)g * p.N + sc_off);
+    sc[slot] = load_dwords<ND>(sc_e + (size_t)g * SW + sc_off);
   };
   auto issue_b = [&](int c, int slot) {
 #pragma unroll
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
 
   auto consume = [&](int c, int slot, int bslot) {
     Dwords<ND> zz;
-    if constexpr (HAS_ZC) zz = load_dwords<ND>(zc_e + (size_t)((c * CS * 32) / p.G) * p.N + sc_off);
+    if constexpr (HAS_ZC) zz = load_dwords<ND>(zc_e + (size_t)((c * CS * 32) / p.G) * SW + sc_off);
     f32x4 acc[NS], acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NS; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
   const int cpw_total = CPW * p.bursts;
   const int cfirst = wave * cpw_total;  // this wave's chunks: [cfirst, cfirst + cpw_total)
 
-  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
   // ---- requests, oldest first: single-row prologue inputs, scales, then the weight burst
   const int vecs_row = p.K >> 3;
   u32x4 xa[BURST_XV], xb[BURST_XV], xw[BURST_XV];
@@ -751,8 +760,8 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
 #pragma unroll
   for (int i = 0; i < SR; i++) {
     const int d = threadIdx.x + i * nthreads;
-    if (d < sdw) {
-      const size_t off = (size_t)(d / SD) * p.N + (size_t)strip * SW + 2 * (d % SD);
+    if (d < sdw) {   // strip-major: the strip's groups x SW scales are contiguous
+      const size_t off = (size_t)strip * sdw * 2 + 2 * (size_t)d;
       s_reg[i] = *reinterpret_cast<const uint32_t*>(p.scales + off);
       if constexpr (HAS_ZC) z_reg[i] = *reinterpret_cast<const uint32_t*>(p.zc + off);
     }
@@ -777,11 +786,12 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
     }
   }
   for (int d = threadIdx.x + SR * nthreads; d < sdw; d += nthreads) {
-    const size_t off = (size_t)(d / SD) * p.N + (size_t)strip * SW + 2 * (d % SD);
+    const size_t off = (size_t)strip * sdw * 2 + 2 * (size_t)d;
     reinterpret_cast<uint32_t*>(sc_l)[d] = *reinterpret_cast<const uint32_t*>(p.scales + off);
     if constexpr (HAS_ZC) reinterpret_cast<uint32_t*>(zc_l)[d] = *reinterpret_cast<const uint32_t*>(p.zc + off);
   }
 
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
   // ---- prologue: activations of this pass -> LDS in the activation dtype
   auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
   auto hi = [](uint32_t u) { return DT::to_f32((uint16_t)(u >> 16)); };
@@ -924,8 +934,9 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
       if constexpr (PRO == PRO_ADDNORM) __syncthreads();  // red is reused by the next row group
     }
   }
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
   __syncthreads();
-  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
   // ---- consume the weight planes in arrival order
   f32x4 tot[NS];
@@ -987,7 +998,7 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
     for (int sub = 0; sub < NS; sub++) *reinterpret_cast<f32x4*>(mine + 4 * sub) = tot[sub];
   }
   __syncthreads();
-  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
   for (int it = threadIdx.x; it < Mt * QW; it += nthreads) {
     const int m_l = it / QW, nq = it % QW;
     const int nl = 4 * nq;
@@ -1014,7 +1025,7 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
       *reinterpret_cast<u32x2*>(p.out + (size_t)(row0 + m_l) * p.N + n) = o;
     }
   }
-  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
 // (NS, CPW) pairs the burst kernel is built for
@@ -1044,9 +1055,9 @@ static BurstPlan plan_burst(int M, int K, int G, int ns, bool has_zc) {
   for (int nw = 16; nw >= 2 && !bp.ok; nw--) {
     if (chunks % nw) continue;
     const int per = chunks / nw;
-    for (int cpw = 7; cpw >= 2; cpw--) {
+    for (int cpw = 8; cpw >= 2; cpw--) {
       if (per % cpw || !burst_built(ns, cpw)) continue;
-      if (cpw * ns >= 7 && nw > 8) continue;  // deep rings are built for 512-thread workgroups
+      if (cpw * ns >= 7 && nw > 8) continue;   // deep rings are built for 512-thread workgroups
       bp.ok = true; bp.nw = nw; bp.cpw = cpw; bp.bursts = per / cpw;
       break;
     }
@@ -1298,8 +1309,9 @@ __global__ __launch_bounds__(256) void dequantize_kernel(const uint32_t* __restr
     int sh;
     packed_pos(K, sw, k0, n, &d, &sh);
     const int g = k0 / G;
-    const float s = DT::to_f32(scales[(size_t)g * N + n]);
-    const float z = zc ? DT::to_f32(zc[(size_t)g * N + n]) - DT::int4_bias : 8.0f;
+    const size_t si = scale_idx(g, n, K / G, sw);
+    const float s = DT::to_f32(scales[si]);
+    const float z = zc ? DT::to_f32(zc[si]) - DT::int4_bias : 8.0f;
     const uint32_t w = wp[d];
 #pragma unroll
     for (int j = 0; j < 8; j++) {

@@ -85,7 +85,17 @@ def w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tens
     else:
         check(L.mi355q_w4a16_repack_host(qweight.data_ptr(), _ptr(qzeros if zc is not None else None),
                                          packed.data_ptr(), _ptr(zc), K, N, G, tile, src_layout, zp_mode, act))
-    return PackedW4(packed, scales.contiguous(), zc, K, N, G, tile, pair_halves)
+    # strip-major scales, [N / tile][K / G][tile]: one contiguous run per workgroup (zc comes out that way)
+    scales = scales.reshape(K // G, N // tile, tile).permute(1, 0, 2).contiguous()
+    if zc is not None:
+        zc = zc.view(N // tile, K // G, tile)
+    return PackedW4(packed, scales, zc, K, N, G, tile, pair_halves)
+
+
+def scales_row_major(w: PackedW4, zc: bool = False) -> torch.Tensor:
+    """The [K/G, N] view of a repacked weight's scales (or zc) -- inverse of the strip-major storage."""
+    t = w.zc if zc else w.scales
+    return t.reshape(w.N // w.tile, w.K // w.G, w.tile).permute(1, 0, 2).reshape(w.K // w.G, w.N)
 
 
 _WS: dict = {}
@@ -262,8 +272,8 @@ def moe_w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.
         raise RuntimeError(f"moe qzeros must be uint8 [{E}, {N // 2}, {K // G}]")
     tile = _lib.lib().mi355q_w4a16_choose_tile(K, N, G)
     packed = torch.empty((E, K * N // 8), dtype=torch.int32, device=qweight.device)
-    sc = torch.empty((E, K // G, N), dtype=scales.dtype, device=qweight.device)
-    zc = None if qzeros is None else torch.empty((E, K // G, N), dtype=scales.dtype, device=qweight.device)
+    sc = torch.empty((E, N // tile, K // G, tile), dtype=scales.dtype, device=qweight.device)
+    zc = None if qzeros is None else torch.empty((E, N // tile, K // G, tile), dtype=scales.dtype, device=qweight.device)
     for e in range(E):
         # four bytes = eight consecutive k, least significant nibble first: the GPTQ word, transposed
         qw = qweight[e].contiguous().view(torch.int32).t().contiguous()              # [K/8, N]
@@ -276,7 +286,7 @@ def moe_w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.
         packed[e].copy_(w.packed)
         sc[e].copy_(w.scales)
         if zc is not None:
-            zc[e].copy_(w.zc)
+            zc[e].copy_(w.zc.view(N // tile, K // G, tile))
     return PackedMoeW4(packed, sc, zc, E, K, N, G, tile)
 
 

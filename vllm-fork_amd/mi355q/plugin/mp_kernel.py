@@ -81,8 +81,8 @@ class MI355XW4A16LinearKernel(MPLinearKernel):
 
     After process_weights_after_loading the layer holds
       <w_q>  : int32 [K*N/8]   kernel tile layout (ops.w4a16_repack)
-      <w_s>  : act  [K/G, N]   group scales, checkpoint values
-      w_zc   : act  [K/G, N]   (magic bias + zero point) per group, asymmetric formats only
+      <w_s>  : act  [N/tile, K/G, tile]  group scales, checkpoint values, strip-major
+      w_zc   : act  [N/tile, K/G, tile]  (magic bias + zero point) per group, asymmetric formats only
     and `mi355q_weight`, the ops.PackedW4 view over them that apply_weights passes to the GEMM.
 
     Accepted checkpoint layouts, told apart by the loader attributes of the parameters:
