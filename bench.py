@@ -139,12 +139,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: MI355Q_DIST_BACKEND=gloo MI355Q_SHARE_GPU=1 lets all ranks use GPU 0
+    share = os.environ.get("MI355Q_SHARE_GPU") == "1"
+    dev_index = 0 if (world == 1 or share) else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+        backend = os.environ.get("MI355Q_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            torch.distributed.init_process_group(backend)
+        warm = torch.ones(8, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(warm)       # communicator set-up happens outside any graph capture
+        torch.cuda.synchronize()
     n_gpus = max(args.gpus, world)
     assert world == n_gpus or world == 1 and n_gpus == 1, "launch with torch.distributed.run for --gpus > 1"
 
@@ -156,7 +164,7 @@ def main():
     B, in_len = args.batch, args.input_len
     max_len = in_len + args.warmup + args.steps + 8
     max_len = (max_len + 255) // 256 * 256
-    dev = f"cuda:{local_rank if world > 1 else 0}"
+    dev = f"cuda:{dev_index}"
     runner = LlamaRunner(cfg, quant=args.quant, kv_cache_dtype=args.kv_dtype, group_size=G, device=dev,
                          tp_rank=rank, tp_size=world, max_batch=B, max_seq_len=max_len)
     torch.cuda.synchronize()
@@ -183,7 +191,7 @@ def main():
         runner.reset(in_len)
 
     # ---- decode ------------------------------------------------------------------------------
-    graph = not args.no_graph
+    graph = not args.no_graph and not (world > 1 and torch.distributed.get_backend() == "gloo")
     if graph:
         try:
             runner.capture()

@@ -193,9 +193,18 @@ class LlamaRunner:
             else sum(K * N * 2 for K, N in linear_shapes(self.cfg, self.tp_size).values()) * self.cfg.layers + \
             self.cfg.vocab // self.tp_size * self.cfg.hidden * 2
 
+    def _host_staged(self) -> bool:
+        """gloo (CPU rehearsal of the multi-GPU path): collectives go through host memory."""
+        return torch.distributed.get_backend(self.tp_group) == "gloo"
+
     def _all_reduce(self, x):
         if self.tp_size > 1:
-            torch.distributed.all_reduce(x, group=self.tp_group)
+            if self._host_staged():
+                t = x.cpu()
+                torch.distributed.all_reduce(t, group=self.tp_group)
+                x.copy_(t)
+            else:
+                torch.distributed.all_reduce(x, group=self.tp_group)
         return x
 
     def _layer(self, L, li, h, residual, positions, slot_mapping, attend):
@@ -246,9 +255,10 @@ class LlamaRunner:
         M = h.shape[0]
         logits = ops.linear_skinny(h, self.lm_head) if M <= 16 else torch.nn.functional.linear(h, self.lm_head)
         if self.tp_size > 1:
-            parts = [torch.empty_like(logits) for _ in range(self.tp_size)]
-            torch.distributed.all_gather(parts, logits, group=self.tp_group)
-            logits = torch.cat(parts, dim=-1)
+            src = logits.cpu() if self._host_staged() else logits
+            parts = [torch.empty_like(src) for _ in range(self.tp_size)]
+            torch.distributed.all_gather(parts, src, group=self.tp_group)
+            logits = torch.cat(parts, dim=-1).to(logits.device)
         return logits
 
     # ------------------------------------------------------------------
