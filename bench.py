@@ -44,11 +44,11 @@ def parse():
     return ap.parse_args()
 
 
-def time_dominant_kernel(runner, batch, reps=6):
+def time_dominant_kernel(runner, batch, reps=10):
     """Per-launch duration of the gate_up W4A16 GEMM (the kernel that moves most bytes of a
-    decode step), measured with an event pair around every launch on the launch stream.  The
-    launches walk over all layers' weights so no launch finds its weights in the 256 MiB
-    Infinity Cache."""
+    decode step), measured with an event pair on the launch stream around graph replays of
+    back-to-back launches.  The launches walk over all layers' weights so no launch finds its
+    weights in the 256 MiB Infinity Cache."""
     from mi355q import ops
     from mi355q.model import linear_shapes, w4a16_bytes
     K, N = linear_shapes(runner.cfg, runner.tp_size)["gate_up"]
@@ -67,17 +67,30 @@ def time_dominant_kernel(runner, batch, reps=6):
     for L in layers[:4]:
         launch(L)
     torch.cuda.synchronize()
-    times = []
-    for _ in range(reps):
-        evs = []
-        for L in layers:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
+    # One graph holds `passes` walks over all layers' launches, so the event pair around a replay
+    # brackets back-to-back kernels only (an event pair around every single launch adds the events'
+    # own barrier packets, several microseconds, to each sample).
+    passes = 4
+    stream = torch.cuda.Stream(device=runner.device)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        for L in layers[:2]:
             launch(L)
-            b.record()
-            evs.append((a, b))
-        torch.cuda.synchronize()
-        times += [a.elapsed_time(b) * 1e-3 for a, b in evs]
+        stream.synchronize()
+        with torch.cuda.graph(graph, stream=stream):
+            for _ in range(passes):
+                for L in layers:
+                    launch(L)
+        graph.replay()
+        stream.synchronize()
+        times = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            graph.replay()
+            b.record(stream)
+            stream.synchronize()
+            times.append(a.elapsed_time(b) * 1e-3 / (passes * len(layers)))
     avg = sum(times) / len(times)
     nbytes = w4a16_bytes(batch, K, N, runner.G, runner.quant == "awq")
     if fused:   # + residual in/out and norm weight of the prologue; the SiLU epilogue writes N/2 per row
@@ -85,10 +98,30 @@ def time_dominant_kernel(runner, batch, reps=6):
         if layers[0]["gate_up"].w.pair_halves:
             nbytes -= batch * (N // 2) * 2
     return {"bound": "hbm", "achieved": nbytes / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": nbytes / avg / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac": nbytes / avg / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(runner, batch, fused),
             "kernel": "w4a16_burst_kernel (gate_up_proj %dx%d + add/RMSNorm prologue + SiLU epilogue, M=%d)" % (K, N, batch),
-            "bytes_per_launch": nbytes, "avg_launch_us": avg * 1e6, "min_launch_us": min(times) * 1e6,
-            "launches": len(times)}
+            "bytes_per_launch": nbytes, "avg_launch_us": avg * 1e6, "min_launch_us": min(times) * 1e6,  # best replay, per launch
+           
+            "launches": len(times) * passes * len(layers)}
+
+
+def pmc_traffic(runner, batch, fused):
+    """HBM bytes per launch of the dominant kernel from the committed counter passes (rocprofv3
+    cannot run inside this process): 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of
+    16-byte-per-lane streaming reads at 64 bytes) + WRITE_SIZE, both KiB per dispatch.  Only
+    valid for the workload the passes were taken on (Llama-3-8B GPTQ, TP=1, batch 1); None
+    otherwise."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1",
+                        "decode_8b_gptq_pmc_fetch_write.json")
+    if not (fused and batch == 1 and runner.tp_size == 1 and runner.cfg.name == "llama3-8b"
+            and runner.quant == "gptq" and os.path.exists(path)):
+        return None
+    with open(path) as fh:
+        rows = json.load(fh)
+    for name, row in rows.items():
+        if "w4a16_burst_kernel<mi355q::BF16, 7, 2, false, 2>" in name:
+            return (2.0 * row["fetch_size_kb_avg"] + row["write_size_kb_avg"]) * 1024.0
+    return None
 
 
 def cpu_baseline(cfg, G, batch, budget_s=15.0):
