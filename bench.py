@@ -59,6 +59,8 @@ def time_dominant_kernel(runner, batch, reps=10):
 
     def launch(L):   # the gate_up launch of a decode step, as LlamaRunner._layer issues it
         if not fused:
+            if runner.quant != "none" and L["gate_up"].w.pair_halves:
+                return ops.w4a16_gate_up_silu(x, None, None, runner.cfg.rms_eps, L["gate_up"].w, add_norm=False)
             return L["gate_up"](x)
         if L["gate_up"].w.pair_halves:
             return ops.w4a16_gate_up_silu(x, residual, L["ln2"], runner.cfg.rms_eps, L["gate_up"].w)
@@ -93,13 +95,14 @@ def time_dominant_kernel(runner, batch, reps=10):
             times.append(a.elapsed_time(b) * 1e-3 / (passes * len(layers)))
     avg = sum(times) / len(times)
     nbytes = w4a16_bytes(batch, K, N, runner.G, runner.quant == "awq")
-    if fused:   # + residual in/out and norm weight of the prologue; the SiLU epilogue writes N/2 per row
+    if fused:   # + residual in/out and norm weight of the prologue
         nbytes += 3 * batch * K * 2 + K * 2
-        if layers[0]["gate_up"].w.pair_halves:
-            nbytes -= batch * (N // 2) * 2
+    if runner.quant != "none" and layers[0]["gate_up"].w.pair_halves:   # the SiLU epilogue writes N/2 per row
+        nbytes -= batch * (N // 2) * 2
     return {"bound": "hbm", "achieved": nbytes / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": nbytes / avg / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(runner, batch, fused),
-            "kernel": "w4a16_burst_kernel (gate_up_proj %dx%d + add/RMSNorm prologue + SiLU epilogue, M=%d)" % (K, N, batch),
+            "kernel": "w4a16_burst_kernel (gate_up_proj %dx%d%s + SiLU epilogue, M=%d)"
+                      % (K, N, " + add/RMSNorm prologue" if fused else "", batch),
             "bytes_per_launch": nbytes, "avg_launch_us": avg * 1e6, "min_launch_us": min(times) * 1e6,  # best replay, per launch
            
             "launches": len(times) * passes * len(layers)}

@@ -99,6 +99,40 @@ def test_w4a16_vs_oracle(M, K, N, G, split):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("M,K,N,G,awq,dt", [(8, 14336, 4096, 128, False, orc.BF16), (16, 4096, 4096, 128, False, orc.BF16),
+                                            (32, 14336, 4096, 128, False, orc.BF16), (21, 1024, 256, 256, True, orc.FP16),
+                                            (5, 3584, 8192, 128, True, orc.BF16), (9, 1024, 8192, 512, False, orc.FP16),
+                                            (33, 2048, 128, 128, False, orc.BF16)])
+def test_w4a16_several_rows_on_narrow_strips(M, K, N, G, awq, dt):
+    """5 or more rows against a 16-channel-strip weight (row-parallel o_proj / down_proj shapes at
+    decode batch 8..32): adjacent strips side by side, K sliced over workgroups, fp32 partial
+    tiles summed in slice order.  Same bar as the single-row kernel, and run-to-run identical."""
+    rng = np.random.default_rng(M * 7 + N)
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    a = orc.f32_to_h16(0.25 * rng.standard_normal((M, K)).astype(np.float32), dt)
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N))).astype(np.float32), dt)
+    bias = orc.f32_to_h16(rng.standard_normal(N).astype(np.float32), dt)
+    if awq:
+        z = rng.integers(0, 16, size=(K // G, N), dtype=np.int32)
+        qw, qz = orc.pack_cols(q, awq_order=True), orc.pack_cols(z, awq_order=True)
+        ref = orc.w4a16_gemm(a, qw, s, qz, bias, G=G, dt=dt, layout=orc.W_AWQ, zp_mode=orc.ZP_AWQ)
+        w = ops.w4a16_repack(i32(qw), to_dev(s, dt), i32(qz), G, _lib.W_AWQ, _lib.ZP_AWQ, tile=16)
+    else:
+        qw = orc.gptq_pack(q)
+        ref = orc.w4a16_gemm(a, qw, s, None, bias, G=G, dt=dt)
+        w = ops.w4a16_repack(i32(qw), to_dev(s, dt), None, G, tile=16)
+    assert w.tile == 16
+    out = ops.w4a16_gemm(to_dev(a, dt), w, bias=to_dev(bias, dt))
+    np.testing.assert_allclose(f32(to_bits(out), dt), f32(ref, dt), rtol=1e-2, atol=1e-2)
+    assert (to_bits(out) == ref).mean() > (0.98 if dt == orc.BF16 else 0.9)
+    for _ in range(3):
+        assert torch.equal(out, ops.w4a16_gemm(to_dev(a, dt), w, bias=to_dev(bias, dt)))
+    # the arrival counters are back at zero: a single-row split-K GEMM on the same workspace still works
+    a1 = a[:1]
+    out1 = ops.w4a16_gemm(to_dev(a1, dt), w, bias=to_dev(bias, dt), split_k=4)
+    assert np.array_equal(to_bits(out1), to_bits(out[:1])) or np.allclose(f32(to_bits(out1), dt), f32(to_bits(out[:1]), dt), rtol=1e-2, atol=1e-2)
+
+
 def test_w4a16_many_token_route_vs_oracle(monkeypatch):
     """Above the token threshold the weight is dequantised to 16-bit and fed to a dense GEMM
     (exllama reconstruct route, csrc/quantization/gptq/q_gemm.cu:1509-1522): compare with the
@@ -183,7 +217,8 @@ def test_w4a16_rejects_bad_shapes():
 # ---------------------------------------------------------------------------
 # unquantized skinny linear
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("M,K,N", [(1, 4096, 1000), (3, 768, 517), (8, 4096, 256), (13, 1024, 129), (2, 8192, 64)])
+@pytest.mark.parametrize("M,K,N", [(1, 4096, 1000), (3, 768, 517), (8, 4096, 256), (13, 1024, 129), (2, 8192, 64),
+                                   (16, 4096, 2000), (12, 8200, 300), (5, 136, 48), (8, 4096, 128256)])
 def test_linear_skinny(M, K, N):
     rng = np.random.default_rng(M + N)
     a = orc.f32_to_h16(rng.standard_normal((M, K)).astype(np.float32))

@@ -3,6 +3,9 @@
 // streams whole weight rows with 16-byte lane loads (1 KiB contiguous per wave
 // instruction), the activations sit in LDS, products run on v_dot2_f32 with fp32
 // accumulation, and a wave64 shuffle tree finishes each row.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mi355q {
@@ -85,9 +88,79 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const uint16_t* __re
   }
 }
 
+// 2..16 activation rows per pass: the weight rows are the MFMA A operand straight from global
+// memory (lane (kq, ml) loads the 16 bytes k0 + 8 kq .. of weight row n0 + ml; a lane's
+// consecutive k-steps are consecutive 64-byte pieces of its row), the activation rows are the B
+// operand from LDS, so the cost per weight byte no longer grows with the row count.
+template <typename DT>
+__global__ __launch_bounds__(512) void linear_mfma_kernel(const uint16_t* __restrict__ a, int lda,
+                                                          const uint16_t* __restrict__ w,
+                                                          const uint16_t* __restrict__ bias,
+                                                          uint16_t* __restrict__ c, int M, int N, int K,
+                                                          int rows_pp, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* xs = reinterpret_cast<uint16_t*>(smem);  // [rows_pp][K + 8]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kq = lane >> 4, ml = lane & 15;
+  const int m0 = blockIdx.y * rows_pp;
+  const int mb = min(rows_pp, M - m0);
+  const int kv = K >> 3, astride = K + 8;
+  for (int idx = threadIdx.x; idx < mb * kv; idx += 512) {
+    const int m = idx / kv, v = idx - m * kv;
+    *reinterpret_cast<u32x4*>(xs + (size_t)m * astride + 8 * v) =
+        *reinterpret_cast<const u32x4*>(a + (size_t)(m0 + m) * lda + 8 * v);
+  }
+  __syncthreads();
+  const int n_begin = blockIdx.x * rows_per_block;
+  const int n_end = min(N, n_begin + rows_per_block);
+  const uint16_t* arow = xs + (size_t)min(ml, mb - 1) * astride + 8 * kq;
+  for (int n0 = n_begin + wave * 16; n0 < n_end; n0 += 8 * 16) {
+    const uint16_t* wrow = w + (size_t)min(n0 + ml, N - 1) * K + 8 * kq;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k0 = 0;
+    for (; k0 + 256 <= K; k0 += 256) {
+      u32x4 wf[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) wf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + k0 + 32 * j));
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        acc0 = mfma16<DT>(wf[j], *reinterpret_cast<const u32x4*>(arow + k0 + 32 * j), acc0);
+        acc1 = mfma16<DT>(wf[j + 1], *reinterpret_cast<const u32x4*>(arow + k0 + 32 * j + 32), acc1);
+      }
+    }
+    for (; k0 < K; k0 += 32)
+      acc0 = mfma16<DT>(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + k0)),
+                        *reinterpret_cast<const u32x4*>(arow + k0), acc0);
+    // lane (kq, ml) holds outputs of activation row ml, weight rows n0 + 4 kq + r
+    if (ml < mb) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int n = n0 + 4 * kq + r;
+        if (n < n_end) {
+          const float v = acc0[r] + acc1[r];
+          c[(size_t)(m0 + ml) * N + n] =
+              bias ? DT::from_f32(DT::to_f32(DT::from_f32(v)) + DT::to_f32(bias[n])) : DT::from_f32(v);
+        }
+      }
+    }
+  }
+}
+
 template <typename DT>
 static int launch_linear(const void* a, int lda, const void* w, const void* bias, void* c, int M,
                          int N, int K, hipStream_t stream) {
+  if (M >= 2 && K % 32 == 0 && !getenv("MI355Q_LINEAR_NO_MFMA")) {
+    int rows_pp = std::min(M, 16);
+    while (rows_pp > 1 && (size_t)rows_pp * (K + 8) * 2 > 128 * 1024) rows_pp--;
+    const size_t lds_m = (size_t)rows_pp * (K + 8) * 2;
+    if (lds_m <= 128 * 1024) {
+      const int rpb = 128;
+      dim3 grid((N + rpb - 1) / rpb, (M + rows_pp - 1) / rows_pp), block(512);
+      hipLaunchKernelGGL((linear_mfma_kernel<DT>), grid, block, lds_m, stream, (const uint16_t*)a, lda,
+                         (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)c, M, N, K, rows_pp, rpb);
+      return check_launch("linear_mfma_kernel");
+    }
+  }
   // rows of A per pass: bounded by 64 KiB of LDS for the staged activations
   int MB = M >= 8 ? 8 : (M >= 4 ? 4 : (M >= 2 ? 2 : 1));
   while (MB > 1 && (size_t)MB * K * 2 > 64 * 1024) MB >>= 1;

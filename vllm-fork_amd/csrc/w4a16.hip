@@ -1160,6 +1160,274 @@ static int launch_skinny(const SkinnyParams& p, int sw, int CS, hipStream_t stre
   return launch_sw<DT, 16, PRO>(p, CS, stream, lds);
 }
 
+// ---------------------------------------------------------------------------
+// Rows kernel: several activation rows (5 <= M, 16 per pass) against a 16-channel-strip layout.
+//
+// With M rows a workgroup must take in M K 2 bytes of activations next to its weights, and a CU
+// ingests ~10 B/cycle whatever the source.  One workgroup per 16-channel strip over the whole
+// of K (the single-row shape) would make every CU read the entire activation matrix, several
+// times its weights.  Here a workgroup owns SPB adjacent strips (their runs are read side by side:
+// same layout, no repack) and 1/splits of K, so both its weights and its activation slice are
+// K N / 2 / 256-ish bytes; the K-slices meet through fp32 partial tiles in the workspace, and the
+// workgroup that draws the last arrival ticket of a tile sums them in slice order (deterministic).
+// ---------------------------------------------------------------------------
+struct RowsParams {
+  const uint16_t* x;
+  int ldx;
+  const u32x4* wp;
+  const uint16_t* scales;
+  const uint16_t* zc;
+  const uint16_t* bias;
+  uint16_t* out;
+  float* partial;   // [splits][M][N]
+  int* counters;    // [row passes][N / (16 SPB)], zero between launches
+  int M, N, K;
+  int chunks;       // K / 128
+  int gchunks;      // chunks per scale group
+  int cps;          // chunks per K-slice = nw * CPW * bursts
+  int splits, nw, bursts, rows_pp;
+};
+
+template <typename DT, int SPB, int CPW, bool HAS_ZC>
+__global__ __launch_bounds__(512) void w4a16_rows_kernel(const RowsParams p) {
+  constexpr int BW = 16 * SPB, QB = BW / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nw = p.nw, nthreads = nw * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int vstrip = blockIdx.x, sp = blockIdx.y;
+  const int kq = lane >> 4, ml = lane & 15;
+  const int row0 = blockIdx.z * p.rows_pp;
+  const int Mt = min(p.rows_pp, p.M - row0);
+  const int kc0 = sp * p.cps;
+  const int Ks = p.cps * 128, astride = Ks + 8;
+  const int groups = p.chunks / p.gchunks;
+  const int g_first = kc0 / p.gchunks;
+  const int gps = (kc0 + p.cps - 1) / p.gchunks - g_first + 1;
+
+  float* red = reinterpret_cast<float*>(smem);                                   // [nw][rows_pp][BW]
+  uint16_t* sc_l = reinterpret_cast<uint16_t*>(smem + (size_t)nw * p.rows_pp * BW * 4);  // [SPB][gps][16]
+  uint16_t* zc_l = sc_l + (size_t)SPB * gps * 16;
+  int* flag = reinterpret_cast<int*>(zc_l + (HAS_ZC ? (size_t)SPB * gps * 16 : 0));
+  uint16_t* act = reinterpret_cast<uint16_t*>(flag + 4);                         // [rows_pp][astride]
+
+  // ---- this wave's weight planes first (for most shapes: everything it will consume) ...
+  const int per_wave = CPW * p.bursts;
+  const int cfirst = kc0 + wave * per_wave;
+  const u32x4* wbase = p.wp + (size_t)vstrip * SPB * p.chunks * 64 + lane;
+  u32x4 w[CPW][SPB];
+  auto issue_chunk = [&](int burst, int i) {
+    const size_t c = (size_t)(cfirst + burst * CPW + i);
+#pragma unroll
+    for (int sub = 0; sub < SPB; sub++)
+      w[i][sub] = __builtin_nontemporal_load(wbase + ((size_t)sub * p.chunks + c) * 64);
+  };
+#pragma unroll
+  for (int i = 0; i < CPW; i++) issue_chunk(0, i);
+
+  // ---- ... then the slice's scales and activation rows -> LDS
+  for (int d = threadIdx.x; d < SPB * gps * 8; d += nthreads) {
+    const int sub = d / (gps * 8), r = d - sub * gps * 8;     // r: dword within the strip's slice run
+    const size_t off = ((size_t)(vstrip * SPB + sub) * groups + g_first) * 16 + 2 * (size_t)r;
+    reinterpret_cast<uint32_t*>(sc_l)[d] = *reinterpret_cast<const uint32_t*>(p.scales + off);
+    if constexpr (HAS_ZC) reinterpret_cast<uint32_t*>(zc_l)[d] = *reinterpret_cast<const uint32_t*>(p.zc + off);
+  }
+  const int vecs = Ks >> 3, total = Mt * vecs;
+  for (int base = threadIdx.x; base < total; base += 4 * nthreads) {
+    u32x4 t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int idx = base + j * nthreads;
+      if (idx < total) {
+        const int m = idx / vecs, v = idx - m * vecs;
+        t[j] = *reinterpret_cast<const u32x4*>(p.x + (size_t)(row0 + m) * p.ldx + (size_t)kc0 * 128 + 8 * v);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int idx = base + j * nthreads;
+      if (idx < total) {
+        const int m = idx / vecs, v = idx - m * vecs;
+        *reinterpret_cast<u32x4*>(act + (size_t)m * astride + 8 * v) = t[j];
+      }
+    }
+  }
+  __syncthreads();
+
+  auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
+  auto hi = [](uint32_t u) { return DT::to_f32((uint16_t)(u >> 16)); };
+  f32x4 tot[SPB];
+#pragma unroll
+  for (int i = 0; i < SPB; i++) tot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
+  const uint16_t* arow = act + (size_t)min(ml, Mt - 1) * astride + 8 * kq;
+
+  for (int burst = 0; burst < p.bursts; burst++) {
+#pragma unroll
+    for (int i = 0; i < CPW; i++) {
+      const int c = cfirst + burst * CPW + i;
+      f32x4 acc[SPB], acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < SPB; s++) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const u32x4 bf = *reinterpret_cast<const u32x4*>(arow + ((c - kc0) * 4 + ks) * 32);
+        acc1 = mfma16<DT>(ones, bf, acc1);
+#pragma unroll
+        for (int sub = 0; sub < SPB; sub++) acc[sub] = mfma16<DT>(dequant_frag<DT>(w[i][sub][ks]), bf, acc[sub]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // this lane's outputs: channels 16 sub + 4 kq + r of the workgroup's BW
+      const int gl = c / p.gchunks - g_first;
+#pragma unroll
+      for (int sub = 0; sub < SPB; sub++) {
+        const u32x2 sv = *reinterpret_cast<const u32x2*>(sc_l + ((size_t)sub * gps + gl) * 16 + 4 * kq);
+        u32x2 zv = u32x2{0u, 0u};
+        if constexpr (HAS_ZC) zv = *reinterpret_cast<const u32x2*>(zc_l + ((size_t)sub * gps + gl) * 16 + 4 * kq);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float s = (r & 1) ? hi(sv[r >> 1]) : lo(sv[r >> 1]);
+          float z;
+          if constexpr (HAS_ZC) z = (r & 1) ? hi(zv[r >> 1]) : lo(zv[r >> 1]);
+          else z = DT::int4_bias + 8.0f;
+          const float d = __builtin_fmaf(-z, acc1[r], acc[sub][r]);
+          tot[sub][r] = __builtin_fmaf(s, d, tot[sub][r]);
+        }
+      }
+      if (burst + 1 < p.bursts) issue_chunk(burst + 1, i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- cross-wave reduction through LDS
+  if (ml < Mt) {
+    float* mine = red + ((size_t)wave * p.rows_pp + ml) * BW + 4 * kq;
+#pragma unroll
+    for (int sub = 0; sub < SPB; sub++) *reinterpret_cast<f32x4*>(mine + 16 * sub) = tot[sub];
+  }
+  __syncthreads();
+
+  typedef unsigned long long u64;
+  auto block_sum = [&](int m_l, int nl) {
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < nw; i++) a += *reinterpret_cast<const f32x4*>(red + ((size_t)i * p.rows_pp + m_l) * BW + nl);
+    return a;
+  };
+  auto finish = [&](int m, int n, f32x4 a) {
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (p.bias) {  // bias is added to the rounded GEMM result, as output.add_(bias) does
+      const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = DT::to_f32(DT::from_f32(v[j]));
+      v[0] += lo(bb[0]); v[1] += hi(bb[0]); v[2] += lo(bb[1]); v[3] += hi(bb[1]);
+    }
+    u32x2 o;
+    o[0] = pack2<DT>(v[0], v[1]);
+    o[1] = pack2<DT>(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(p.out + (size_t)m * p.N + n) = o;
+  };
+
+  if (p.splits == 1) {
+    for (int it = threadIdx.x; it < Mt * QB; it += nthreads) {
+      const int m_l = it / QB, nl = 4 * (it % QB);
+      finish(row0 + m_l, vstrip * BW + nl, block_sum(m_l, nl));
+    }
+    return;
+  }
+  // publish this slice's tile with write-through (agent-scope) stores, then draw a ticket
+  for (int it = threadIdx.x; it < Mt * QB; it += nthreads) {
+    const int m_l = it / QB, nl = 4 * (it % QB);
+    const f32x4 a = block_sum(m_l, nl);
+    u64* dst = reinterpret_cast<u64*>(p.partial + ((size_t)sp * p.M + row0 + m_l) * p.N + vstrip * BW + nl);
+    __hip_atomic_store(dst, (u64)__float_as_uint(a[0]) | ((u64)__float_as_uint(a[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 1, (u64)__float_as_uint(a[2]) | ((u64)__float_as_uint(a[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int* cnt = p.counters + (size_t)blockIdx.z * gridDim.x + vstrip;
+    const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == p.splits - 1;
+    if (last) {
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  for (int it = threadIdx.x; it < Mt * QB; it += nthreads) {
+    const int m_l = it / QB, nl = 4 * (it % QB);
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.splits; s++) {
+      const u64* src = reinterpret_cast<const u64*>(p.partial + ((size_t)s * p.M + row0 + m_l) * p.N + vstrip * BW + nl);
+      const u64 l = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 h = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a[0] += __uint_as_float((uint32_t)l);
+      a[1] += __uint_as_float((uint32_t)(l >> 32));
+      a[2] += __uint_as_float((uint32_t)h);
+      a[3] += __uint_as_float((uint32_t)(h >> 32));
+    }
+    finish(row0 + m_l, vstrip * BW + nl, a);
+  }
+}
+
+constexpr int ROWS_SPB = 4;
+constexpr int ROWS_MIN_M = 5;
+
+struct RowsPlan {
+  bool ok;
+  int splits, nw, cpw, bursts, rows_pp;
+  size_t lds;
+};
+
+// K-slices so that (N / 64) x slices is about one workgroup per CU, each slice an exact
+// nw x cpw x bursts of 128-k chunks; rows per pass from what the LDS holds.
+static RowsPlan plan_rows(int M, int N, int K, int G, bool has_zc) {
+  RowsPlan rp{false, 0, 0, 0, 0, 0, 0};
+  if (G % 128 || K % 128 || N % (16 * ROWS_SPB)) return rp;
+  const int chunks = K / 128, gchunks = G / 128, vstrips = N / (16 * ROWS_SPB);
+  int best_score = -1;
+  for (int s = 1; s <= 16; s++) {
+    if (chunks % s || vstrips * s > 320) continue;
+    const int cps = chunks / s;
+    for (int nw = 8; nw >= 1; nw--) {
+      if (cps % nw) continue;
+      const int per = cps / nw;
+      for (int cpw = 4; cpw >= 2; cpw -= 2) {
+        if (per % cpw) continue;
+        // prefer the slice count that fills the chip, then bytes in flight per CU, then waves
+        const int fill = std::min(vstrips * s, 256);
+        const int score = fill * 1000 + std::min(nw * cpw, 32) * 10 + nw;
+        if (score > best_score) {
+          best_score = score;
+          rp.ok = true; rp.splits = s; rp.nw = nw; rp.cpw = cpw; rp.bursts = per / cpw;
+        }
+      }
+    }
+  }
+  if (!rp.ok) return rp;
+  const int cps = chunks / rp.splits;
+  const int gps = (cps + gchunks - 1) / gchunks + 1;   // upper bound on the groups a slice touches
+  const size_t fixed = (size_t)ROWS_SPB * gps * 16 * 2 * (has_zc ? 2 : 1) + 16;
+  const size_t row = (size_t)(cps * 128 + 8) * 2 + (size_t)rp.nw * 16 * ROWS_SPB * 4;
+  if (fixed + row > 160 * 1024) { rp.ok = false; return rp; }
+  rp.rows_pp = (int)std::min<size_t>(16, (160 * 1024 - fixed) / row);
+  rp.rows_pp = std::min(rp.rows_pp, M);
+  rp.lds = fixed + (size_t)rp.rows_pp * row;
+  return rp;
+}
+
+template <typename DT>
+static int launch_rows(const RowsParams& p, int cpw, size_t lds, hipStream_t stream) {
+  dim3 grid(p.N / (16 * ROWS_SPB), p.splits, (p.M + p.rows_pp - 1) / p.rows_pp), block(p.nw * 64);
+#define MI355Q_R(c, z) hipLaunchKernelGGL((w4a16_rows_kernel<DT, ROWS_SPB, c, z>), grid, block, lds, stream, p)
+  if (cpw == 4) { if (p.zc) MI355Q_R(4, true); else MI355Q_R(4, false); }
+  else { if (p.zc) MI355Q_R(2, true); else MI355Q_R(2, false); }
+#undef MI355Q_R
+  return check_launch("w4a16_rows_kernel");
+}
+
 struct NormArgs {
   const void* res_in;
   void* res_out;
@@ -1187,6 +1455,28 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
   MI355Q_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)scales & 15) == 0 &&
                      ((uintptr_t)c & 7) == 0 && ((uintptr_t)zc & 15) == 0 && ((uintptr_t)bias & 7) == 0,
                  "w4a16_gemm: pointers must be 16-byte aligned");
+  // several rows against the 16-channel-strip layout: strips side by side, K sliced over workgroups
+  if (!moe && pro == PRO_NONE && !epi_silu && sw == 16 && M >= ROWS_MIN_M && !getenv("MI355Q_NO_ROWS")) {
+    RowsPlan rp = plan_rows(M, N, K, G, zc != nullptr);
+    // short K: the single-strip kernel still holds every row of a pass in LDS and needs no K-slices
+    const BurstPlan sb = plan_burst(M, K, G, 1, zc != nullptr);
+    if (sb.ok && sb.rows_pp >= std::min(M, 16) && (size_t)std::min(M, 16) * K * 2 <= 96 * 1024) rp.ok = false;
+    const size_t need = COUNTER_BYTES + (size_t)rp.splits * M * N * sizeof(float);
+    const bool ws_ok = rp.splits == 1 || (workspace && ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= need &&
+                                          (size_t)(N / (16 * ROWS_SPB)) * ((M + rp.rows_pp - 1) / std::max(rp.rows_pp, 1)) * sizeof(int) <= COUNTER_BYTES);
+    if (rp.ok && ws_ok) {
+      RowsParams r;
+      r.x = (const uint16_t*)x; r.ldx = ldx; r.wp = (const u32x4*)packed;
+      r.scales = (const uint16_t*)scales; r.zc = (const uint16_t*)zc; r.bias = (const uint16_t*)bias;
+      r.out = (uint16_t*)c;
+      r.counters = (int*)workspace;
+      r.partial = workspace ? (float*)((char*)workspace + COUNTER_BYTES) : nullptr;
+      r.M = M; r.N = N; r.K = K; r.chunks = K / 128; r.gchunks = G / 128;
+      r.splits = rp.splits; r.cps = r.chunks / rp.splits; r.nw = rp.nw; r.bursts = rp.bursts; r.rows_pp = rp.rows_pp;
+      return act_dtype == MI355Q_BF16 ? launch_rows<BF16>(r, rp.cpw, rp.lds, stream)
+                                      : launch_rows<FP16>(r, rp.cpw, rp.lds, stream);
+    }
+  }
   // decode path: one burst workgroup per strip whenever the strips alone occupy the chip
   if (!moe) {
     const int ns = sw / 16;

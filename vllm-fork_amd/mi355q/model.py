@@ -7,6 +7,7 @@ down_proj), GPTQ/AWQ 4-bit linears, a 16-bit lm_head and greedy sampling, with t
 column/row tensor-parallel split of vllm/model_executor/layers/linear.py (all-reduce
 after o_proj and down_proj, linear.py:1763-1767).  Weights are synthetic.
 """
+import os
 from dataclasses import dataclass
 
 import torch
@@ -28,6 +29,9 @@ class LlamaConfig:
     rms_eps: float = 1e-5
     max_pos: int = 8192
 
+
+# token counts up to which add+RMSNorm runs in the prologue of the GEMM that consumes it
+FUSE_NORM_MAX_TOKENS = int(os.environ.get("MI355Q_FUSE_NORM_MAX", "4"))
 
 CONFIGS = {
     "llama3-8b": LlamaConfig("llama3-8b", 4096, 14336, 32, 32, 8, 128, 128256),
@@ -211,7 +215,7 @@ class LlamaRunner:
         cfg, D = self.cfg, self.cfg.head_dim
         T = h.shape[0]
         # small token counts: the add+RMSNorm runs in the prologue of the GEMM that consumes it
-        fuse_norm = self.quant != "none" and T <= 4
+        fuse_norm = self.quant != "none" and T <= FUSE_NORM_MAX_TOKENS
         if fuse_norm:
             qkv, residual = ops.w4a16_gemm_add_rms_norm(h, residual, L["ln1"], cfg.rms_eps, L["qkv"].w)
         else:
@@ -238,8 +242,13 @@ class LlamaRunner:
                                   slot_mapping, self.kv_cache_dtype, self.k_scale, self.v_scale)
             attend(li, q.view(T, self.heads, D), attn)
         o = self._all_reduce(L["o"](attn.view(T, qs)))
-        if fuse_norm and L["gate_up"].w.pair_halves:
-            act, residual = ops.w4a16_gate_up_silu(o, residual, L["ln2"], cfg.rms_eps, L["gate_up"].w)
+        if self.quant != "none" and L["gate_up"].w.pair_halves and T <= ops.DEQUANT_MATMUL_MIN_TOKENS:
+            # decode-sized batches: SiluAndMul in the gate_up epilogue (and the norm in its prologue)
+            if fuse_norm:
+                act, residual = ops.w4a16_gate_up_silu(o, residual, L["ln2"], cfg.rms_eps, L["gate_up"].w)
+            else:
+                ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
+                act, _ = ops.w4a16_gate_up_silu(o, None, None, cfg.rms_eps, L["gate_up"].w, add_norm=False)
             d = self._all_reduce(L["down"](act))
             return d, residual
         if fuse_norm:
