@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-bf16", action="store_true")
     ap.add_argument("--skip-ttft", action="store_true")
+    ap.add_argument("--skip-shapes", action="store_true", help="skip the other (batch, input_len) shapes")
     return ap.parse_args()
 
 
@@ -288,7 +289,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, G, B)
     if rank == 0 and n_gpus == 1 and args.quant != "none" and not args.skip_bf16:
         # the same harness on the unquantized model: the "x its own bf16 decode" comparator
-        del runner
+        runner = None
         torch.cuda.empty_cache()
         r16 = LlamaRunner(cfg, quant="none", kv_cache_dtype=args.kv_dtype, device=dev, max_batch=B, max_seq_len=max_len)
         r16.reset(in_len)
@@ -305,6 +306,39 @@ def main():
         s16 = (time.perf_counter() - t0) / n16
         out["bf16_tok_s"] = B / s16
         out["speedup_vs_bf16"] = s16 / step_s
+    if rank == 0 and n_gpus == 1 and args.quant != "none" and not args.skip_shapes and (B, in_len) == (1, 128):
+        # the other fixed (batch, input_len) shapes of the latency benchmark, same model and harness
+        runner = r16 = None
+        out["other_shapes"] = []
+        for b2, in2 in ((1, 2048), (8, 32), (32, 1024)):
+            torch.cuda.empty_cache()
+            ml2 = (in2 + 4 + 32 + 8 + 255) // 256 * 256
+            r2 = LlamaRunner(cfg, quant=args.quant, kv_cache_dtype=args.kv_dtype, group_size=G, device=dev,
+                             max_batch=b2, max_seq_len=ml2)
+            p2 = torch.randint(0, min(10000, cfg.vocab), (b2, in2), generator=torch.Generator().manual_seed(0))
+            ts = []
+            for i in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r2.prefill(p2)
+                torch.cuda.synchronize()
+                if i >= 2:
+                    ts.append(time.perf_counter() - t0)
+            if graph:
+                r2.capture()
+            for _ in range(4):
+                r2.decode_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(32):
+                r2.decode_step()
+            torch.cuda.synchronize()
+            s2 = (time.perf_counter() - t0) / 32
+            bytes2 = decode_bytes_per_step(cfg, b2, in2 + 4 + 16, G, args.quant == "awq", kv_bytes, world)
+            out["other_shapes"].append({"batch": b2, "input_len": in2, "tok_s": b2 / s2, "ms_per_step": s2 * 1e3,
+                                        "ttft_ms_p50": statistics.median(ts) * 1e3,
+                                        "step_hbm_frac": bytes2 / s2 / 1e9 / HBM_PEAK_GBS})
+            del r2
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -167,6 +167,28 @@ int mi355q_w4a16_gemm_add_rms_norm(const void* x, int ldx, const void* residual_
                                    int split_k, mi355q_stream_t stream);
 
 /*
+ * The same GEMM for many rows (prompt processing; worthwhile from 17 rows): a tiled matrix-core
+ * kernel that reads the packed weight once per 64 rows instead of expanding it to 16 bits first.
+ * Same arithmetic as mi355q_w4a16_gemm (fp32 (q - z) * s, one rounding, bias after rounding).
+ * Replaces the many-token routes of the reference: exllama reconstruct + hipBLAS
+ * (q_gemm.cu:1509-1522), awq_dequantize + matmul (auto_awq.py:947-955) and the large-M tiles of
+ * triton_w4a16_gemm (triton_w4a16.py:164-270).
+ *   silu_pairs : 1 = weight repacked with MI355Q_W_PAIR_HALVES, write
+ *                c[M, N/2] = silu(y[:, 2i]) * y[:, 2i+1] (no bias), as mi355q_w4a16_gate_up_silu
+ *   workspace  : >= mi355q_w4a16_mm_workspace_bytes(M, N, K, G, tile) bytes of device memory (fp32
+ *                partial tiles of layers whose K is sliced over workgroups; 0 for wide layers).
+ *                Needs no initialisation; GEMMs sharing it must be ordered on one stream.
+ * Requires G % 128 == 0 and N a multiple of 256 (448 for 112-wide strips):
+ * mi355q_w4a16_mm_supported(N, K, G, tile) tells; callers fall back to
+ * mi355q_w4a16_dequantize + a dense GEMM otherwise.
+ */
+size_t mi355q_w4a16_mm_workspace_bytes(int M, int N, int K, int G, int tile);
+int mi355q_w4a16_mm_supported(int N, int K, int G, int tile);
+int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const void* scales, const void* zc,
+                    const void* bias, void* c, int M, int N, int K, int G, int tile, int act_dtype,
+                    int silu_pairs, void* workspace, size_t workspace_bytes, mi355q_stream_t stream);
+
+/*
  * gate_up projection with SiluAndMul in its epilogue, for weights repacked with
  * MI355Q_W_PAIR_HALVES: c[M, N/2] = silu(y[:, 2i]) * y[:, 2i+1] with y = the GEMM above
  * (rounded to act_dtype first, silu rounded before the multiply: the arithmetic of

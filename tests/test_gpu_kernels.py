@@ -18,6 +18,7 @@ def _kernel_route(monkeypatch):
     """These tests check the skinny W4A16 kernel itself at every M; the dequantise + dense GEMM
     route for long prompts has its own test below."""
     monkeypatch.setattr(ops, "DEQUANT_MATMUL_MIN_TOKENS", 1 << 30)
+    monkeypatch.setattr(ops, "MM_MIN_TOKENS", 1 << 30)
 
 
 def to_dev(bits, dt=orc.BF16):
@@ -131,6 +132,68 @@ def test_w4a16_several_rows_on_narrow_strips(M, K, N, G, awq, dt):
     a1 = a[:1]
     out1 = ops.w4a16_gemm(to_dev(a1, dt), w, bias=to_dev(bias, dt), split_k=4)
     assert np.array_equal(to_bits(out1), to_bits(out[:1])) or np.allclose(f32(to_bits(out1), dt), f32(to_bits(out[:1]), dt), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,K,N,G,tile,awq,dt", [
+    (128, 4096, 28672, 128, 112, False, orc.BF16),   # gate_up: 112-wide strips, 2 K-slices
+    (128, 14336, 4096, 128, 16, False, orc.BF16),    # down: 16-wide strips, 4 side by side per wave, K sliced
+    (17, 4096, 6144, 128, 32, False, orc.BF16),      # qkv: 32-wide strips
+    (200, 1024, 512, 256, 64, True, orc.FP16),       # 64-wide strips, zero points, ragged last row block
+    (64, 512, 256, 128, 16, True, orc.BF16),
+    (333, 2048, 896, 128, 112, False, orc.FP16),
+])
+def test_w4a16_mm_vs_oracle(M, K, N, G, tile, awq, dt):
+    """Tiled matrix-core kernel for prompt-sized token counts: same fp32 (q - z) * s arithmetic as
+    the decode kernels, so the same bar against the oracle (reference tolerance rtol = atol = 1e-2,
+    tests/kernels/quantization/test_triton_w4a16.py:162, and nearly all outputs bit-equal)."""
+    rng = np.random.default_rng(M + K + N)
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    a = orc.f32_to_h16(0.25 * rng.standard_normal((M, K)).astype(np.float32), dt)
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N))).astype(np.float32), dt)
+    bias = orc.f32_to_h16(rng.standard_normal(N).astype(np.float32), dt)
+    if awq:
+        z = rng.integers(0, 16, size=(K // G, N), dtype=np.int32)
+        qw, qz = orc.pack_cols(q, awq_order=True), orc.pack_cols(z, awq_order=True)
+        ref = orc.w4a16_gemm(a, qw, s, qz, bias, G=G, dt=dt, layout=orc.W_AWQ, zp_mode=orc.ZP_AWQ)
+        w = ops.w4a16_repack(i32(qw), to_dev(s, dt), i32(qz), G, _lib.W_AWQ, _lib.ZP_AWQ, tile=tile)
+    else:
+        qw = orc.gptq_pack(q)
+        ref = orc.w4a16_gemm(a, qw, s, None, bias, G=G, dt=dt)
+        w = ops.w4a16_repack(i32(qw), to_dev(s, dt), None, G, tile=tile)
+    assert w.tile == tile
+    out = ops.w4a16_mm(to_dev(a, dt), w, bias=to_dev(bias, dt))
+    # the bias is added to the ROUNDED product (reference semantics), so a one-ulp difference of a
+    # large product can survive a cancelling bias as a large relative error of a small sum: allow
+    # a few such outputs per million, each within one ulp of the product's magnitude
+    got, want = f32(to_bits(out), dt), f32(ref, dt)
+    bad = ~np.isclose(got, want, rtol=1e-2, atol=1e-2)
+    assert bad.mean() < 1e-5
+    prod_mag = np.abs(want - f32(bias, dt)[None, :]) + 1.0
+    assert np.all(np.abs(got - want)[bad] <= prod_mag[bad] * (2.0 ** -7 if dt == orc.BF16 else 2.0 ** -10))
+    assert (to_bits(out) == ref).mean() > (0.98 if dt == orc.BF16 else 0.9)
+    assert torch.equal(out, ops.w4a16_mm(to_dev(a, dt), w, bias=to_dev(bias, dt)))
+
+
+def test_w4a16_mm_silu_pairs_and_routing(monkeypatch):
+    """pair_halves weight + SiLU epilogue = silu_and_mul of the plain projection; w4a16_gemm routes
+    17..1024 tokens to the tiled kernel and refuses nothing it used to serve."""
+    rng = np.random.default_rng(5)
+    M, K, I, G = 96, 1024, 1792, 128
+    N = 2 * I
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    a = orc.f32_to_h16(0.5 * rng.standard_normal((M, K)).astype(np.float32))
+    s = orc.f32_to_h16((0.03 * rng.random((K // G, N)) + 0.005).astype(np.float32))
+    qw = orc.gptq_pack(q)
+    y = orc.w4a16_gemm(a, qw, s, None, None, G=G)
+    ref = orc.silu_and_mul(y)
+    w = ops.w4a16_repack(i32(qw), to_dev(s), None, G, pair_halves=True)
+    act = ops.w4a16_mm(to_dev(a), w, silu_pairs=True)
+    assert act.shape == (M, I)
+    np.testing.assert_allclose(f32(to_bits(act)), f32(ref), rtol=2e-2, atol=1e-2)
+    assert (to_bits(act) == ref).mean() > 0.97
+    monkeypatch.setattr(ops, "MM_MIN_TOKENS", 17)
+    plain = ops.unpair_halves(ops.w4a16_gemm(to_dev(a), w))
+    assert (to_bits(plain) == y).mean() > 0.98
 
 
 def test_w4a16_many_token_route_vs_oracle(monkeypatch):

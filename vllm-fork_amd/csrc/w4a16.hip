@@ -1428,6 +1428,246 @@ static int launch_rows(const RowsParams& p, int cpw, size_t lds, hipStream_t str
   return check_launch("w4a16_rows_kernel");
 }
 
+// ---------------------------------------------------------------------------
+// Many-row kernel (prompt processing, 17+ rows): a workgroup of four waves computes a
+// [16 RT rows] x [4 waves x CT 16-channel subtiles] tile over one K-slice.  The activation
+// chunk [rows x 128 k] is staged in LDS (double-buffered, shared by the four waves); every wave
+// streams the planes of its own SPW strips straight into registers -- they already are MFMA
+// operand fragments -- one chunk ahead of use.  Same arithmetic as the decode kernels: per
+// 128-k chunk acc = sum a (bias + q) and a1 = sum a on the matrix cores, then
+// tot += s (acc - (bias + z) a1) in fp32; one rounding at the end.  K-slices (layers too narrow
+// to occupy the chip otherwise) leave fp32 partial tiles that a second kernel sums in slice order.
+// ---------------------------------------------------------------------------
+struct MmParams {
+  const uint16_t* x;
+  int ldx;
+  const u32x4* wp;
+  const uint16_t* scales;
+  const uint16_t* zc;
+  const uint16_t* bias;
+  uint16_t* out;
+  float* partial;   // [splits][M][N] when splits > 1
+  int M, N, K;
+  int chunks, gchunks, cps, splits;
+  int epi_silu;
+};
+
+template <typename DT>
+__device__ inline void mm_store(const MmParams& p, int row, int n, f32x4 a) {
+  auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
+  auto hi = [](uint32_t u) { return DT::to_f32((uint16_t)(u >> 16)); };
+  float v[4] = {a[0], a[1], a[2], a[3]};
+  if (p.bias) {  // bias is added to the rounded GEMM result, as output.add_(bias) does
+    const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = DT::to_f32(DT::from_f32(v[j]));
+    v[0] += lo(bb[0]); v[1] += hi(bb[0]); v[2] += lo(bb[1]); v[3] += hi(bb[1]);
+  }
+  if (p.epi_silu) {
+    const float g0 = DT::to_f32(DT::from_f32(v[0])), u0 = DT::to_f32(DT::from_f32(v[1]));
+    const float g1 = DT::to_f32(DT::from_f32(v[2])), u1 = DT::to_f32(DT::from_f32(v[3]));
+    const float s0 = DT::to_f32(DT::from_f32(silu_f(g0))), s1 = DT::to_f32(DT::from_f32(silu_f(g1)));
+    *reinterpret_cast<uint32_t*>(p.out + (size_t)row * (p.N >> 1) + (n >> 1)) = pack2<DT>(s0 * u0, s1 * u1);
+  } else {
+    u32x2 o;
+    o[0] = pack2<DT>(v[0], v[1]);
+    o[1] = pack2<DT>(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(p.out + (size_t)row * p.N + n) = o;
+  }
+}
+
+template <typename DT, int NS, int SPW, int RT, bool HAS_ZC>
+__global__ __launch_bounds__(256) void w4a16_mm_kernel(const MmParams p) {
+  constexpr int CT = NS * SPW, SW = 16 * NS, QW = 4 * NS, BM = 16 * RT;
+  constexpr int ASTR = 128 + 8;  // LDS row stride (elements): 16 bytes of padding per row
+  __shared__ __attribute__((aligned(16))) uint16_t abuf[2][BM * ASTR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kq = lane >> 4, ml = lane & 15;
+  const int strip0 = (blockIdx.x * 4 + wave) * SPW;
+  const int row0 = blockIdx.y * BM;
+  const int c0 = blockIdx.z * p.cps, c1 = c0 + p.cps;
+  const int groups = p.chunks / p.gchunks;
+  const int srow = threadIdx.x >> 4, sseg = threadIdx.x & 15;
+
+  auto load_acts = [&](int c, u32x4 (&t)[RT]) {
+#pragma unroll
+    for (int i = 0; i < RT; i++) {
+      const int r = min(row0 + srow + 16 * i, p.M - 1);
+      t[i] = *reinterpret_cast<const u32x4*>(p.x + (size_t)r * p.ldx + (size_t)c * 128 + 8 * sseg);
+    }
+  };
+  auto store_acts = [&](int buf, const u32x4 (&t)[RT]) {
+#pragma unroll
+    for (int i = 0; i < RT; i++) *reinterpret_cast<u32x4*>(&abuf[buf][(srow + 16 * i) * ASTR + 8 * sseg]) = t[i];
+  };
+  auto load_w = [&](int c, u32x4 (&w)[CT]) {
+#pragma unroll
+    for (int j = 0; j < SPW; j++)
+#pragma unroll
+      for (int pl = 0; pl < NS; pl++)
+        w[j * NS + pl] = p.wp[(((size_t)(strip0 + j) * p.chunks + c) * NS + pl) * 64 + lane];
+  };
+  auto load_s = [&](int c, u32x2 (&sv)[CT], u32x2 (&zv)[CT]) {
+    const int g = c / p.gchunks;
+#pragma unroll
+    for (int j = 0; j < SPW; j++)
+#pragma unroll
+      for (int sub = 0; sub < NS; sub++) {
+        const size_t off = ((size_t)(strip0 + j) * groups + g) * SW + QW * kq + 4 * sub;
+        sv[j * NS + sub] = *reinterpret_cast<const u32x2*>(p.scales + off);
+        if constexpr (HAS_ZC) zv[j * NS + sub] = *reinterpret_cast<const u32x2*>(p.zc + off);
+      }
+  };
+  auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
+  auto hi = [](uint32_t u) { return DT::to_f32((uint16_t)(u >> 16)); };
+
+  u32x4 wc[CT], wn[CT], an[RT];
+  u32x2 sc[CT], sn[CT], zv[CT], zn[CT];
+  load_w(c0, wc);
+  load_s(c0, sc, zv);
+  load_acts(c0, an);
+  store_acts(0, an);
+  __syncthreads();
+
+  f32x4 tot[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) tot[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
+
+  for (int c = c0; c < c1; c++) {
+    const int cur = (c - c0) & 1;
+    const bool more = c + 1 < c1;
+    if (more) {
+      load_w(c + 1, wn);
+      load_s(c + 1, sn, zn);
+      load_acts(c + 1, an);
+    }
+    f32x4 acc[RT][CT], acc1[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+      acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      u32x4 bf[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) {
+        bf[rt] = *reinterpret_cast<const u32x4*>(&abuf[cur][(16 * rt + ml) * ASTR + 32 * ks + 8 * kq]);
+        acc1[rt] = mfma16<DT>(ones, bf[rt], acc1[rt]);
+      }
+#pragma unroll
+      for (int j = 0; j < SPW; j++)
+#pragma unroll
+        for (int sub = 0; sub < NS; sub++) {
+          const int e = ks * NS + sub;
+          const u32x4 wf = dequant_frag<DT>(wc[j * NS + (e >> 2)][e & 3]);
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++) acc[rt][j * NS + sub] = mfma16<DT>(wf, bf[rt], acc[rt][j * NS + sub]);
+        }
+    }
+    // lane (kq, ml): rows 16 rt + ml, channels QW kq + 4 sub + r of each strip
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float s = (r & 1) ? hi(sc[ct][r >> 1]) : lo(sc[ct][r >> 1]);
+        float z;
+        if constexpr (HAS_ZC) z = (r & 1) ? hi(zv[ct][r >> 1]) : lo(zv[ct][r >> 1]);
+        else z = DT::int4_bias + 8.0f;
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+          tot[rt][ct][r] = __builtin_fmaf(s, __builtin_fmaf(-z, acc1[rt][r], acc[rt][ct][r]), tot[rt][ct][r]);
+      }
+    }
+    if (more) {
+      store_acts(cur ^ 1, an);
+#pragma unroll
+      for (int i = 0; i < CT; i++) { wc[i] = wn[i]; sc[i] = sn[i]; if constexpr (HAS_ZC) zv[i] = zn[i]; }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    const int row = row0 + 16 * rt + ml;
+    if (row >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < SPW; j++)
+#pragma unroll
+      for (int sub = 0; sub < NS; sub++) {
+        const int n = SW * (strip0 + j) + QW * kq + 4 * sub;
+        if (p.splits > 1)
+          *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.z * p.M + row) * p.N + n) = tot[rt][j * NS + sub];
+        else
+          mm_store<DT>(p, row, n, tot[rt][j * NS + sub]);
+      }
+  }
+}
+
+template <typename DT>
+__global__ __launch_bounds__(256) void w4a16_mm_reduce_kernel(const MmParams p) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;   // 4 consecutive channels of one row
+  const size_t nq = (size_t)p.N >> 2;
+  if (q >= (size_t)p.M * nq) return;
+  const int row = (int)(q / nq), n = 4 * (int)(q - (size_t)row * nq);
+  f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < p.splits; sp++) a += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)sp * p.M + row) * p.N + n);
+  mm_store<DT>(p, row, n, a);
+}
+
+constexpr int MM_RT = 4;
+
+struct MmPlan {
+  bool ok;
+  int ns, spw, splits;
+  size_t ws;   // bytes of fp32 partial tiles
+};
+
+static MmPlan plan_mm(int M, int N, int K, int G, int sw) {
+  MmPlan mp{false, 0, 0, 1, 0};
+  if (G % 128 || K % 128 || sw % 16) return mp;
+  const int ns = sw / 16;
+  if (ns != 1 && ns != 2 && ns != 4 && ns != 7) return mp;
+  const int spw = ns == 1 ? 4 : (ns == 2 ? 2 : 1);
+  const int bw = 4 * spw * sw;
+  if (N % bw) return mp;
+  const int chunks = K / 128;
+  const long tiles = (long)(N / bw) * ((M + 16 * MM_RT - 1) / (16 * MM_RT));
+  int s = 1;
+  while (tiles * s < 200 && s < 16 && chunks % (s * 2) == 0 && chunks / (s * 2) >= 2) s *= 2;
+  if (tiles * s < 200) {   // odd factors of the chunk count (K = 14336 = 128 * 112 = 128 * 16 * 7)
+    for (int f = 7; f >= 3; f -= 2)
+      if (chunks % (s * f) == 0 && chunks / (s * f) >= 2 && tiles * s * f <= 512) { s *= f; break; }
+  }
+  mp.ok = true; mp.ns = ns; mp.spw = spw; mp.splits = s;
+  mp.ws = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+  return mp;
+}
+
+template <typename DT>
+static int launch_mm(const MmParams& p, const MmPlan& mp, hipStream_t stream) {
+  const int bw = 4 * mp.spw * 16 * mp.ns;
+  dim3 grid(p.N / bw, (p.M + 16 * MM_RT - 1) / (16 * MM_RT), p.splits), block(256);
+#define MI355Q_MM(NS_, SPW_)                                                                              \
+  if (mp.ns == NS_) {                                                                                     \
+    if (p.zc) hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, MM_RT, true>), grid, block, 0, stream, p);  \
+    else hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, MM_RT, false>), grid, block, 0, stream, p);      \
+  }
+  MI355Q_MM(1, 4) else MI355Q_MM(2, 2) else MI355Q_MM(4, 1) else MI355Q_MM(7, 1)
+#undef MI355Q_MM
+  if (int e = check_launch("w4a16_mm_kernel")) return e;
+  if (p.splits > 1) {
+    const size_t items = (size_t)p.M * (p.N >> 2);
+    hipLaunchKernelGGL((w4a16_mm_reduce_kernel<DT>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p);
+    return check_launch("w4a16_mm_reduce_kernel");
+  }
+  return MI355Q_OK;
+}
+
 struct NormArgs {
   const void* res_in;
   void* res_out;
@@ -1737,3 +1977,47 @@ extern "C" int mi355q_w4a16_gate_up_silu_supported(int K, int N, int G, int tile
 /* Diagnostics: when set, every burst-kernel workgroup writes four 100 MHz timestamps (entry,
  * activations staged, weights consumed, done) at stamps[4 * strip ..].  Not part of the public ABI. */
 extern "C" void mi355q_debug_burst_stamps(void* stamps) { g_burst_stamps = (unsigned long long*)stamps; }
+
+/* ---- many rows (prompt processing) ------------------------------------------- */
+extern "C" size_t mi355q_w4a16_mm_workspace_bytes(int M, int N, int K, int G, int tile) {
+  if (G <= 0) G = K;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const MmPlan mp = plan_mm(M, N, K, G, tile);
+  return mp.ok ? mp.ws : 0;
+}
+
+extern "C" int mi355q_w4a16_mm_supported(int N, int K, int G, int tile) {
+  if (G <= 0) G = K;
+  if (N <= 0 || K <= 0 || tile <= 0 || N % tile || !tile_ok(tile, K, G)) return 0;
+  return plan_mm(64, N, K, G, tile).ok ? 1 : 0;
+}
+
+extern "C" int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const void* scales, const void* zc,
+                               const void* bias, void* c, int M, int N, int K, int G, int tile, int act_dtype,
+                               int silu_pairs, void* workspace, size_t workspace_bytes, mi355q_stream_t stream) {
+  if (int e = check_shape(K, N, G)) return e;
+  if (int e = check_tile(tile, K, G, N)) return e;
+  MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w4a16_mm: act_dtype must be bf16 or fp16");
+  if (M == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(a && packed && scales && c && M > 0, "w4a16_mm: bad arguments");
+  MI355Q_REQUIRE(lda % 8 == 0 && lda >= K, "w4a16_mm: row stride %d must be a multiple of 8 and cover the row", lda);
+  MI355Q_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)scales & 15) == 0 &&
+                     ((uintptr_t)c & 7) == 0 && ((uintptr_t)zc & 15) == 0 && ((uintptr_t)bias & 7) == 0,
+                 "w4a16_mm: pointers must be 16-byte aligned");
+  MI355Q_REQUIRE(!silu_pairs || bias == nullptr, "w4a16_mm: the SiLU-pair epilogue takes no bias");
+  const MmPlan mp = plan_mm(M, N, K, G, tile);
+  MI355Q_REQUIRE(mp.ok, "w4a16_mm: needs a group size that is a multiple of 128 and N a multiple of %d for strip width %d",
+                 tile == 112 ? 448 : 256, tile);
+  MmParams p;
+  p.x = (const uint16_t*)a; p.ldx = lda; p.wp = (const u32x4*)packed;
+  p.scales = (const uint16_t*)scales; p.zc = (const uint16_t*)zc; p.bias = (const uint16_t*)bias;
+  p.out = (uint16_t*)c; p.partial = nullptr;
+  p.M = M; p.N = N; p.K = K; p.chunks = K / 128; p.gchunks = G / 128;
+  p.splits = mp.splits; p.cps = p.chunks / mp.splits; p.epi_silu = silu_pairs ? 1 : 0;
+  if (mp.splits > 1) {
+    MI355Q_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "w4a16_mm: K-slices need a 16-byte aligned workspace");
+    if (workspace_bytes < mp.ws) return set_error(MI355Q_ENOSPACE, "w4a16_mm: workspace %zu B < %zu B", workspace_bytes, mp.ws);
+    p.partial = (float*)workspace;
+  }
+  return act_dtype == MI355Q_BF16 ? launch_mm<BF16>(p, mp, (hipStream_t)stream) : launch_mm<FP16>(p, mp, (hipStream_t)stream);
+}

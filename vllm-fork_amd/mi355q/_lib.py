@@ -45,6 +45,10 @@ _SIGS = {
     "mi355q_w4a16_gate_up_silu": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp,
                                           c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_w4a16_gate_up_silu_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "mi355q_w4a16_mm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_vp, c_sz, c_vp]),
+    "mi355q_w4a16_mm_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
+    "mi355q_w4a16_mm_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "mi355q_topk_softmax": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_moe_w4a16_gemm": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_vp]),

@@ -242,15 +242,21 @@ class LlamaRunner:
                                   slot_mapping, self.kv_cache_dtype, self.k_scale, self.v_scale)
             attend(li, q.view(T, self.heads, D), attn)
         o = self._all_reduce(L["o"](attn.view(T, qs)))
-        if self.quant != "none" and L["gate_up"].w.pair_halves and T <= ops.DEQUANT_MATMUL_MIN_TOKENS:
-            # decode-sized batches: SiluAndMul in the gate_up epilogue (and the norm in its prologue)
-            if fuse_norm:
-                act, residual = ops.w4a16_gate_up_silu(o, residual, L["ln2"], cfg.rms_eps, L["gate_up"].w)
-            else:
-                ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
-                act, _ = ops.w4a16_gate_up_silu(o, None, None, cfg.rms_eps, L["gate_up"].w, add_norm=False)
-            d = self._all_reduce(L["down"](act))
-            return d, residual
+        if self.quant != "none" and L["gate_up"].w.pair_halves:
+            gu_w = L["gate_up"].w
+            tiled = ops.MM_MIN_TOKENS <= T <= ops.MM_MAX_TOKENS and ops._mm_supported(gu_w)
+            if T < ops.MM_MIN_TOKENS or tiled:
+                # SiluAndMul in the gate_up epilogue (and, for a few tokens, the norm in its prologue)
+                if fuse_norm:
+                    act, residual = ops.w4a16_gate_up_silu(o, residual, L["ln2"], cfg.rms_eps, gu_w)
+                else:
+                    ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
+                    if tiled:
+                        act = ops.w4a16_mm(o, gu_w, silu_pairs=True)
+                    else:
+                        act, _ = ops.w4a16_gate_up_silu(o, None, None, cfg.rms_eps, gu_w, add_norm=False)
+                d = self._all_reduce(L["down"](act))
+                return d, residual
         if fuse_norm:
             gu, residual = ops.w4a16_gemm_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps, L["gate_up"].w)
         else:

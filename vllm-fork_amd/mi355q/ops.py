@@ -99,7 +99,15 @@ def scales_row_major(w: PackedW4, zc: bool = False) -> torch.Tensor:
 
 
 _WS: dict = {}
+_WS_RETIRED: list = []
 DEQUANT_MATMUL_MIN_TOKENS = 32
+# token range served by the tiled matrix-core W4A16 kernel (below: the decode kernels; above: dequantise
+# once + dense GEMM, compute-bound and best left to the BLAS)
+MM_MIN_TOKENS = 17
+MM_MAX_TOKENS = 512
+
+
+COUNTER_BYTES = 64 * 1024   # arrival counters at the head of the workspace; partial tiles follow
 
 
 def _workspace(dev, nbytes: int) -> torch.Tensor:
@@ -110,6 +118,8 @@ def _workspace(dev, nbytes: int) -> torch.Tensor:
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("split-K workspace must be sized before graph capture (run the op once eagerly)")
+        if ws is not None:
+            _WS_RETIRED.append(ws)   # captured graphs may still hold its address
         ws = torch.zeros(max(nbytes, 1 << 24), dtype=torch.uint8, device=dev)
         _WS[dev] = ws
     return ws
@@ -131,6 +141,8 @@ def w4a16_gemm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, s
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     M = x2.shape[0]
+    if MM_MIN_TOKENS <= M <= MM_MAX_TOKENS and not fuse_silu_mul and _mm_supported(w):
+        return w4a16_mm(x2, w, bias).reshape(x.shape[:-1] + (w.N,))
     if M > DEQUANT_MATMUL_MIN_TOKENS and not torch.cuda.is_current_stream_capturing():
         # many tokens (prompt processing): dequantise once and run a dense GEMM, as the reference
         # does from 256 tokens on (auto_awq.py:947-955; exllama reconstruct path q_gemm.cu:1509-1522)
@@ -150,6 +162,34 @@ def w4a16_gemm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, s
     check(fn(x2.data_ptr(), x2.stride(0), w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc), _ptr(bias),
              out.data_ptr(), M, w.N, w.K, w.G, w.tile, _dt(x), ws.data_ptr(), ws.numel(), split_k, _stream()))
     return out.reshape(x.shape[:-1] + (w.N,))
+
+
+def _mm_supported(w: PackedW4) -> bool:
+    return bool(_lib.lib().mi355q_w4a16_mm_supported(w.N, w.K, w.G, w.tile))
+
+
+def w4a16_mm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, silu_pairs: bool = False) -> torch.Tensor:
+    """[tokens, K] @ dequant(w) for prompt-sized token counts on the tiled matrix-core kernel: the packed
+    weight is read once per 64 tokens and never expanded in memory.  Stands in for the many-token
+    routes of ops.gptq_gemm (q_gemm.cu:1509-1522) and awq (auto_awq.py:947-955).  With silu_pairs
+    (weight repacked with pair_halves) the output is SiluAndMul of the projection, [tokens, N/2]."""
+    _need_cuda(x, w.packed)
+    if x.dim() != 2 or x.shape[1] != w.K or x.stride(1) != 1:
+        raise RuntimeError(f"w4a16_mm: input must be [tokens, {w.K}] with unit inner stride")
+    if x.dtype != w.scales.dtype:
+        raise RuntimeError(f"activation dtype {x.dtype} != scales dtype {w.scales.dtype}")
+    if silu_pairs and not w.pair_halves:
+        raise RuntimeError("w4a16_mm: silu_pairs needs a weight repacked with pair_halves=True")
+    M = x.shape[0]
+    L = _lib.lib()
+    out = torch.empty((M, w.N // 2 if silu_pairs else w.N), dtype=x.dtype, device=x.device)
+    need = L.mi355q_w4a16_mm_workspace_bytes(M, w.N, w.K, w.G, w.tile)
+    ws = _workspace(x.device, need + COUNTER_BYTES) if need else None
+    check(L.mi355q_w4a16_mm(x.data_ptr(), x.stride(0), w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc), _ptr(bias),
+                            out.data_ptr(), M, w.N, w.K, w.G, w.tile, _dt(x), int(silu_pairs),
+                            ws.data_ptr() + COUNTER_BYTES if ws is not None else None,
+                            ws.numel() - COUNTER_BYTES if ws is not None else 0, _stream()))
+    return out
 
 
 def w4a16_gemm_add_rms_norm(x: torch.Tensor, residual: torch.Tensor | None, norm_weight: torch.Tensor | None,
@@ -381,6 +421,8 @@ def w8a16_gemm(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, bloc
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     M = x2.shape[0]
+    if MM_MIN_TOKENS <= M <= MM_MAX_TOKENS and not fuse_silu_mul and _mm_supported(w):
+        return w4a16_mm(x2, w, bias).reshape(x.shape[:-1] + (w.N,))
     if M > DEQUANT_MATMUL_MIN_TOKENS and not torch.cuda.is_current_stream_capturing():
         out = torch.nn.functional.linear(x2, w8a16_dequantize(weight, scales, block, x.dtype), bias)
         return out.reshape(x.shape[:-1] + (N,))
