@@ -1479,7 +1479,7 @@ __device__ inline void mm_store(const MmParams& p, int row, int n, f32x4 a) {
 template <typename DT, int NS, int SPW, int RT, bool HAS_ZC>
 __global__ __launch_bounds__(256) void w4a16_mm_kernel(const MmParams p) {
   constexpr int CT = NS * SPW, SW = 16 * NS, QW = 4 * NS, BM = 16 * RT;
-  constexpr int ASTR = 128 + 8;  // LDS row stride (elements): 16 bytes of padding per row
+  constexpr int ASTR = 128 + 16;  // LDS row stride (elements): 32 bytes of padding keep ds_read_b128 conflict-free
   __shared__ __attribute__((aligned(16))) uint16_t abuf[2][BM * ASTR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kq = lane >> 4, ml = lane & 15;
