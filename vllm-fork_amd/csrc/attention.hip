@@ -54,8 +54,14 @@ __device__ inline u32x2 fp8x4_to_h16(uint32_t v) {
   const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(v, false);
   const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8(v, true);
   u32x2 r;
-  r[0] = pack2<DT>(lo[0], lo[1]);
-  r[1] = pack2<DT>(hi[0], hi[1]);
+  if constexpr (DT::id == MI355Q_BF16) {
+    // every e4m3 value is a bf16 value: the upper halves of the fp32 words are the result
+    r[0] = (__float_as_uint(lo[0]) >> 16) | (__float_as_uint(lo[1]) & 0xffff0000u);
+    r[1] = (__float_as_uint(hi[0]) >> 16) | (__float_as_uint(hi[1]) & 0xffff0000u);
+  } else {
+    r[0] = pack2<DT>(lo[0], lo[1]);
+    r[1] = pack2<DT>(hi[0], hi[1]);
+  }
   return r;
 }
 
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
     }
   }
   const int64_t pos = FUSED ? p.positions[seq] : 0;
+  const float kscale = KVFP8 ? *p.k_scale : 1.0f, vscale = KVFP8 ? *p.v_scale : 1.0f;  // requested with the rest
   const int seq_len = p.seq_lens[seq];
   const int q_in_blk = min(QB, qlen - q0);
   const int blk_ctx = seq_len - qlen + q0 + q_in_blk;  // tokens visible to the last column
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
   const int qrow = qstart + q0 + min(qi, q_in_blk - 1);
   const int head = kvh * g + min(hi, g - 1);
 
-  const float scale = KVFP8 ? p.scale * (*p.k_scale) : p.scale;
+  const float scale = p.scale * kscale;
   const float slope = p.alibi ? p.alibi[head] : 0.f;
   const int32_t* table = p.block_tables + (size_t)seq * p.max_blocks;
   const int wave_t0 = p0 + wave * 64;
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
         const size_t i1 = base + ((size_t)(d1 / X) * p.bs + off) * X + d1 % X;
         const size_t i2 = base + ((size_t)(d2 / X) * p.bs + off) * X + d2 % X;
         if constexpr (KVFP8) {
-          const float ks = *p.k_scale;
+          const float ks = kscale;
           const uint8_t b1 = f32_to_fp8(DT::to_f32(xr) / ks), b2 = f32_to_fp8(DT::to_f32(yr) / ks);
           reinterpret_cast<uint8_t*>(const_cast<void*>(p.kc))[i1] = b1;
           reinterpret_cast<uint8_t*>(const_cast<void*>(p.kc))[i2] = b2;
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
         const int d = t - 128;
         const size_t vi = base + (size_t)d * p.bs + off;
         if constexpr (KVFP8) {
-          const uint8_t b = f32_to_fp8(DT::to_f32(nv) / *p.v_scale);
+          const uint8_t b = f32_to_fp8(DT::to_f32(nv) / vscale);
           reinterpret_cast<uint8_t*>(const_cast<void*>(p.vc))[vi] = b;
           reinterpret_cast<uint8_t*>(s_vnew)[d] = b;
         } else {
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
 
   PA_STAMP(4);
   // ---- cross-wave sum of O, store ---------------------------------------------------------
-  const float vs = KVFP8 ? *p.v_scale : 1.0f;
+  const float vs = vscale;
 #pragma unroll
   for (int dt = 0; dt < DTILES; dt++)
     *reinterpret_cast<f32x4*>(&s_out[wave][col][dt * 16 + 4 * kq]) = o[dt] * vs;

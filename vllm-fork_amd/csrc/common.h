@@ -64,6 +64,14 @@ template <typename DT>
 __device__ inline uint32_t pack2(float lo, float hi) {
   return (uint32_t)DT::from_f32(lo) | ((uint32_t)DT::from_f32(hi) << 16);
 }
+// bf16 pairs go through the hardware conversion (v_cvt_pk_bf16_f32: round to nearest even, NaN
+// stays NaN) -- one instruction instead of the integer rounding sequence, same values
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_cvt;
+template <>
+__device__ inline uint32_t pack2<BF16>(float lo, float hi) {
+  const f32x2 v = f32x2{lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_cvt));
+}
 
 template <typename DT>
 __device__ inline f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c);
