@@ -1,6 +1,9 @@
 // Memory-bound row kernels: RMSNorm family, RoPE, SiLU-mul, KV-cache write, fp8 convert,
 // sampler inner loop.  One workgroup per token row, 16-byte vector accesses where the row
 // allows it, fp32 arithmetic, wave64 shuffles + one LDS hop for the reductions.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mi355q {
@@ -253,6 +256,85 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const void* __restrict__ l
   }
 }
 
+// Wide rows (a vocabulary): the row is cut into segments, one workgroup each, that read 16 bytes
+// per lane; a segment's best (value, first index) becomes one 64-bit key -- order-preserving
+// image of the float in the upper half, 0x7fffffff - index in the lower -- merged with an atomic
+// max per row, and the workgroup that draws the row's last ticket decodes the key.  The per-row
+// slots live in device memory owned by the library and return to zero after every call, so calls
+// that overlap on one GPU (different streams) must not share rows below ARGMAX_ROWS; they are
+// ordered on one stream in this library's use.
+constexpr int ARGMAX_ROWS = 1024;
+constexpr int ARGMAX_SEG_ELEMS = 8192;
+static __device__ unsigned long long g_argmax_key[ARGMAX_ROWS];
+static __device__ int g_argmax_cnt[ARGMAX_ROWS];
+
+template <int DTID>
+__global__ __launch_bounds__(256) void argmax_wide_kernel(const void* __restrict__ logits, int64_t row_stride,
+                                                          int64_t* __restrict__ ids, int V, int segs) {
+  constexpr int ES = DTID == MI355Q_FP32 ? 4 : 2, EPV = 16 / ES;
+  typedef unsigned long long u64;
+  __shared__ u64 skey[4];
+  const int rowi = blockIdx.x, seg = blockIdx.y;
+  const char* row = reinterpret_cast<const char*>(logits) + (size_t)rowi * row_stride * ES;
+  const int per = ((V + segs - 1) / segs + EPV - 1) / EPV * EPV;   // elements per segment, whole vectors
+  const int e0 = seg * per, e1 = min(V, e0 + per);
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  auto take = [&](float v, int i) {
+    if (v > best) { best = v; bi = i; }   // ascending scan keeps the first index per thread
+  };
+  const int nv = max(e1 - e0, 0) / EPV;
+  for (int v0 = threadIdx.x; v0 < nv; v0 += 4 * 256) {
+    u32x4 t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (v0 + j * 256 < nv) t[j] = *reinterpret_cast<const u32x4*>(row + ((size_t)e0 + (size_t)(v0 + j * 256) * EPV) * ES);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (v0 + j * 256 < nv) {
+        const int i0 = e0 + (v0 + j * 256) * EPV;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if constexpr (DTID == MI355Q_FP32) take(__uint_as_float(t[j][e]), i0 + e);
+          else if constexpr (DTID == MI355Q_BF16) {
+            take(BF16::to_f32((uint16_t)(t[j][e] & 0xffff)), i0 + 2 * e);
+            take(BF16::to_f32((uint16_t)(t[j][e] >> 16)), i0 + 2 * e + 1);
+          } else {
+            take(FP16::to_f32((uint16_t)(t[j][e] & 0xffff)), i0 + 2 * e);
+            take(FP16::to_f32((uint16_t)(t[j][e] >> 16)), i0 + 2 * e + 1);
+          }
+        }
+      }
+  }
+  // a thread's vectors are visited in ascending index order, but `take` on equal values must keep
+  // the smaller index across vectors too: it does (strict >)
+  for (int i = e0 + nv * EPV + threadIdx.x; i < e1; i += 256) take(load_logit<DTID>(row, i), i);
+  const uint32_t fb = __float_as_uint(best);
+  const uint32_t ord = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);
+  u64 key = ((u64)ord << 32) | (uint32_t)(0x7fffffff - bi);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 other = __shfl_xor(key, o, 64);
+    key = other > key ? other : key;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) skey[wave] = key;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w2 = 1; w2 < 4; w2++) key = skey[w2] > key ? skey[w2] : key;
+    __hip_atomic_fetch_max(&g_argmax_key[rowi], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const int ticket = __hip_atomic_fetch_add(&g_argmax_cnt[rowi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == segs - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const u64 k = __hip_atomic_exchange(&g_argmax_key[rowi], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&g_argmax_cnt[rowi], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int idx = 0x7fffffff - (int)(uint32_t)(k & 0xffffffffu);
+      ids[rowi] = idx == 0x7fffffff ? 0 : idx;   // row of -inf / NaN: index 0
+    }
+  }
+}
+
 template <int DTID>
 __global__ void repetition_penalty_kernel(void* __restrict__ logits,
                                           const uint8_t* __restrict__ pm,
@@ -418,6 +500,19 @@ extern "C" int mi355q_argmax(const void* logits, int64_t row_stride, int64_t* id
   MI355Q_REQUIRE(dtype >= MI355Q_BF16 && dtype <= MI355Q_FP32, "argmax: bad dtype");
   if (num_rows == 0) return MI355Q_OK;
   hipStream_t s = (hipStream_t)stream;
+  const int es = dtype == MI355Q_FP32 ? 4 : 2;
+  const int segs = std::min(vocab / ARGMAX_SEG_ELEMS, 64);
+  if (segs >= 2 && num_rows <= ARGMAX_ROWS && ((uintptr_t)logits & 15) == 0 && (row_stride * es) % 16 == 0 &&
+      !getenv("MI355Q_ARGMAX_NARROW")) {
+    const dim3 grid(num_rows, segs);
+    if (dtype == MI355Q_FP32)
+      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_FP32>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs);
+    else if (dtype == MI355Q_BF16)
+      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_BF16>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs);
+    else
+      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_FP16>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs);
+    return check_launch("argmax_wide_kernel");
+  }
   if (dtype == MI355Q_FP32)
     hipLaunchKernelGGL((argmax_kernel<MI355Q_FP32>), dim3(num_rows), dim3(1024), 0, s, logits, row_stride, ids, vocab);
   else if (dtype == MI355Q_BF16)
