@@ -460,6 +460,59 @@ def test_paged_attention_vs_oracle(H, KVH, D, bs, fp8):
     np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-5, atol=2e-3 if not fp8 else 1e-2)
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_paged_attention_inline_merge_equals_merge_kernel(fp8, monkeypatch):
+    """Partitions merged inside the attention kernel (last workgroup to arrive) give the output of
+    the stand-alone merge kernel (to one rounding step), call after call on the same scratch buffers with
+    changing queries and lengths (a stale read of another workgroup's partial would show)."""
+    rng = np.random.default_rng(21)
+    H, KVH, D, bs, S, nblk = 32, 8, 128, 16, 5, 160
+    x = 16 if fp8 else 8
+    scale = D ** -0.5
+    kf = rng.uniform(-1, 1, (nblk, KVH, D // x, bs, x)).astype(np.float32)
+    vf = rng.uniform(-1, 1, (nblk, KVH, D, bs)).astype(np.float32)
+    ks, vs = (1 / 64, 1 / 32) if fp8 else (1.0, 1.0)
+    if fp8:
+        kc, vc = orc.f32_to_e4m3(kf / ks), orc.f32_to_e4m3(vf / vs)
+        kcd, vcd = torch.from_numpy(kc).to(DEV), torch.from_numpy(vc).to(DEV)
+    else:
+        kc, vc = orc.f32_to_h16(kf), orc.f32_to_h16(vf)
+        kcd, vcd = to_dev(kc), to_dev(vc)
+    max_len = 2000
+    maxb = (max_len + bs - 1) // bs
+    P = (max_len + 255) // 256
+    kst = torch.tensor(ks, dtype=torch.float32, device=DEV)
+    vst = torch.tensor(vs, dtype=torch.float32, device=DEV)
+    tmp = torch.empty((S, H, P, D), dtype=torch.bfloat16, device=DEV)
+    es = torch.empty((S, H, P), dtype=torch.float32, device=DEV)
+    ml = torch.empty_like(es)
+    for it in range(4):
+        lens = rng.integers(1, max_len + 1, size=S)
+        lens[it % S] = [1, 256, 257, 2000][it]          # one partition / exact boundary / just past it / maximum
+        q = orc.f32_to_h16(rng.uniform(-1, 1, (S, H, D)).astype(np.float32))
+        bt = rng.integers(0, nblk, size=(S, maxb)).astype(np.int32)
+        sl = np.array(lens, dtype=np.int32)
+        qd = to_dev(q)
+        outs = []
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("MI355Q_PA_REDUCE_KERNEL", env)
+            else:
+                monkeypatch.delenv("MI355Q_PA_REDUCE_KERNEL", raising=False)
+            out = torch.full_like(qd, float("nan"))
+            ops.paged_attention_rocm(out, es, ml, tmp, qd, kcd, vcd, KVH, scale, torch.from_numpy(bt).to(DEV),
+                                     torch.from_numpy(sl).to(DEV), None, bs, max_len, None, "fp8" if fp8 else "auto", kst, vst)
+            outs.append(out)
+        # same formula in two kernels: the compiler may contract the multiply-adds differently, so a
+        # handful of outputs can differ by one rounding step; anything more would be a stale read
+        a, b = outs[0].float(), outs[1].float()
+        assert not torch.isnan(a).any() and not torch.isnan(b).any()
+        assert (a != b).float().mean() < 1e-3, f"iteration {it}"
+        assert torch.allclose(a, b, rtol=2.0 ** -7, atol=1e-6), f"iteration {it}"
+        ref = orc.paged_attention(q, kc, vc, bt, sl, scale, fp8=fp8, k_scale=ks, v_scale=vs)
+        np.testing.assert_allclose(f32(to_bits(outs[0])), f32(ref), rtol=1e-5, atol=2e-3 if not fp8 else 1e-2)
+
+
 def test_paged_attention_skips_prompt_rows_and_ignores_stale_cache():
     """Rows whose query length != 1 are left untouched (csrc/rocm/attention.cu:351-354), and
     cache slots past seq_len may hold NaN without leaking into the output."""

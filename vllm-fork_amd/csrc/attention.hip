@@ -13,6 +13,8 @@
 //                      S^T registers it already holds (no cross-lane traffic)
 // Softmax statistics are combined across waves through LDS; per-partition results go to
 // tmp_out / exp_sums / max_logits and a second kernel merges partitions.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mi355q {
@@ -47,7 +49,14 @@ struct PAParams {
   const uint16_t* cos_sin;  // [max_pos, HEAD] in the activation dtype
   unsigned long long* stamps;  // diagnostics: 10 timestamps per workgroup (8 at 100 MHz, 2 shader-clock), or null
   int k_off, v_off;
+  int inline_reduce;  // 1: the workgroup that finishes a query block's last partition merges the partitions
 };
+
+// Arrival counters of the in-kernel partition merge, one per (query block, kv head); library-owned,
+// zero between launches (the last arriver resets its counter).  Launches that overlap on one GPU
+// must not share counters: they are ordered on one stream in this library's use.
+constexpr int PA_COUNTERS = 65536;
+static __device__ int g_pa_cnt[PA_COUNTERS];
 
 template <typename DT>
 __device__ inline u32x2 fp8x4_to_h16(uint32_t v) {
@@ -94,6 +103,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
   // fused decode step: the new token's rotated key and its value, as the cache will hold them
   __shared__ __attribute__((aligned(16))) uint16_t s_knew[FUSED ? HEAD : 8];
   __shared__ __attribute__((aligned(16))) uint16_t s_vnew[FUSED ? HEAD : 8];
+  __shared__ int s_last;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kq = lane >> 4, col = lane & 15;
@@ -457,7 +467,10 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
     *reinterpret_cast<f32x4*>(&s_out[wave][col][dt * 16 + 4 * kq]) = o[dt] * vs;
   __syncthreads();
 
-  const bool single = p.max_parts == 1;
+  // one partition covers the whole context of this query block: the result is final
+  const int nactive = (blk_ctx + MI355Q_PA_PARTITION - 1) / MI355Q_PA_PARTITION;
+  const bool single = p.max_parts == 1 || (p.inline_reduce && nactive == 1);
+  typedef unsigned long long u64;
   for (int idx = threadIdx.x; idx < 16 * HEAD / 8; idx += 256) {   // 8 consecutive head dims per thread
     const int c = idx / (HEAD / 8), d = (idx - c * (HEAD / 8)) * 8;
     const int cqi = c / gp, chi = c % gp;
@@ -473,17 +486,83 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
     o8[2] = pack2<DT>(hi4[0], hi4[1]); o8[3] = pack2<DT>(hi4[2], hi4[3]);
     const size_t row = (size_t)(qstart + q0 + cqi);
     const int h = kvh * g + chi;
-    uint16_t* dst = single ? reinterpret_cast<uint16_t*>(p.out) + (row * p.num_heads + h) * HEAD + d
-                           : reinterpret_cast<uint16_t*>(p.tmp_out) + ((row * p.num_heads + h) * p.max_parts + part) * HEAD + d;
-    *reinterpret_cast<u32x4*>(dst) = o8;
+    if (single) {
+      *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.out) + (row * p.num_heads + h) * HEAD + d) = o8;
+    } else {
+      uint16_t* dst = reinterpret_cast<uint16_t*>(p.tmp_out) + ((row * p.num_heads + h) * p.max_parts + part) * HEAD + d;
+      if (p.inline_reduce) {   // write-through: another workgroup reads these in this launch
+        __hip_atomic_store(reinterpret_cast<u64*>(dst), (u64)o8[0] | ((u64)o8[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<u64*>(dst) + 1, (u64)o8[2] | ((u64)o8[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        *reinterpret_cast<u32x4*>(dst) = o8;
+      }
+    }
   }
   PA_STAMP(5);
   PA_STAMP(9);
-  if (!single && wave == 0 && kq == 0 && col_valid) {
+  if (single) return;
+  if (wave == 0 && kq == 0 && col_valid) {
     const size_t row = (size_t)(qstart + q0 + qi);
     const size_t o2 = (row * p.num_heads + (kvh * g + hi)) * p.max_parts + part;
-    p.exp_sums[o2] = sum;
-    p.max_logits[o2] = mx;
+    if (p.inline_reduce) {
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(p.exp_sums + o2), __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(p.max_logits + o2), __float_as_uint(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      p.exp_sums[o2] = sum;
+      p.max_logits[o2] = mx;
+    }
+  }
+  if (!p.inline_reduce) return;
+
+  // ---- merge of the partitions by the last workgroup to arrive --------------------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int* cnt = g_pa_cnt + (size_t)blockIdx.x * gridDim.z + blockIdx.z;
+    const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == nactive - 1;
+    if (last) {
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  for (int idx = threadIdx.x; idx < 16 * HEAD / 8; idx += 256) {
+    const int c = idx / (HEAD / 8), d = (idx - c * (HEAD / 8)) * 8;
+    const int cqi = c / gp, chi = c % gp;
+    if (chi >= g || cqi >= q_in_blk) continue;
+    const size_t row = (size_t)(qstart + q0 + cqi);
+    const int h = kvh * g + chi;
+    const int ctx_r = seq_len - qlen + q0 + cqi + 1;
+    const int nparts = (ctx_r + MI355Q_PA_PARTITION - 1) / MI355Q_PA_PARTITION;
+    const size_t base = (row * p.num_heads + h) * p.max_parts;
+    float gmax = -INFINITY;
+    for (int i = 0; i < nparts; i++)
+      gmax = fmaxf(gmax, __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p.max_logits + base + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    float wsum = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint16_t* tmp = reinterpret_cast<const uint16_t*>(p.tmp_out) + base * HEAD + d;
+    for (int i = 0; i < nparts; i++) {
+      const float es = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p.exp_sums + base + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const float ml = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p.max_logits + base + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const float w = es * __expf(ml - gmax);
+      wsum += w;
+      const u64 a = __hip_atomic_load(reinterpret_cast<const u64*>(tmp + (size_t)i * HEAD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 b = __hip_atomic_load(reinterpret_cast<const u64*>(tmp + (size_t)i * HEAD) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t wd[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        acc[2 * e] += DT::to_f32((uint16_t)(wd[e] & 0xffff)) * w;
+        acc[2 * e + 1] += DT::to_f32((uint16_t)(wd[e] >> 16)) * w;
+      }
+    }
+    const float den = wsum + 1e-6f;   // divisions, as the stand-alone merge kernel: identical results
+    u32x4 o8;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o8[e] = pack2<DT>(acc[2 * e] / den, acc[2 * e + 1] / den);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.out) + (row * p.num_heads + h) * HEAD + d) = o8;
   }
 }
 
@@ -526,8 +605,11 @@ __global__ __launch_bounds__(HEAD) void paged_attention_reduce_kernel(const PAPa
 }
 
 template <typename DT>
-static int launch_pa(const PAParams& p, int head_size, int kv_fp8, int qblocks, int max_qlen,
+static int launch_pa(const PAParams& p_in, int head_size, int kv_fp8, int qblocks, int max_qlen,
                      hipStream_t stream, bool fused = false) {
+  PAParams p = p_in;
+  // partitions are merged inside the kernel whenever the library's arrival counters cover the grid
+  p.inline_reduce = p.max_parts > 1 && (long)qblocks * p.num_kv_heads <= PA_COUNTERS && !getenv("MI355Q_PA_REDUCE_KERNEL");
   dim3 grid(qblocks, p.max_parts, p.num_kv_heads), block(256);
 #define MI355Q_PA(H, F8, FU) hipLaunchKernelGGL((paged_attention_kernel<DT, H, F8, FU>), grid, block, 0, stream, p)
   if (fused) {
@@ -537,7 +619,7 @@ static int launch_pa(const PAParams& p, int head_size, int kv_fp8, int qblocks, 
   else { if (kv_fp8) MI355Q_PA(64, true, false); else MI355Q_PA(64, false, false); }
 #undef MI355Q_PA
   if (int e = check_launch("paged_attention_kernel")) return e;
-  if (p.max_parts > 1) {
+  if (p.max_parts > 1 && !p.inline_reduce) {
     dim3 rgrid(p.num_heads, p.num_seqs * max_qlen);
     if (head_size == 128)
       hipLaunchKernelGGL((paged_attention_reduce_kernel<DT, 128>), rgrid, dim3(128), 0, stream, p, max_qlen);
