@@ -5,7 +5,9 @@
  * Every device pointer is memory owned by the caller (torch's caching
  * allocator in the vLLM integration).  No entry point allocates or frees device
  * memory, synchronises the host, or touches any stream other than the one
- * passed in, so all of them can be captured into a HIP graph.
+ * passed in, so all of them can be captured into a HIP graph.  (Two kernels keep
+ * arrival counters in a small static device array of the library: see
+ * mi355q_paged_attention and mi355q_argmax.)
  *
  * Return value: 0 on success, a negative MI355Q_E* code otherwise;
  * mi355q_last_error() returns a thread-local message for the last failure
@@ -339,6 +341,12 @@ int mi355q_convert_fp8(void* dst, const void* src, int64_t n, float scale, int d
  * (vllm/_custom_ops.py:120-163; csrc/rocm/attention.cu:3652-3712): same
  * argument meaning; exp_sums/max_logits [S, H, P] fp32 and tmp_out [S, H, P, D]
  * are caller-allocated scratch with P = ceil(max_seq_len / 256).
+ * The partitions of a long context are merged inside the same launch by the last
+ * workgroup to arrive; its arrival counters are a few KiB of device memory owned by the
+ * library, zero between launches.  Attention launches that overlap on one GPU (different
+ * streams) would share them: keep them on one stream, or set MI355Q_PA_REDUCE_KERNEL=1 in
+ * the environment for the stateless variant with a separate merge launch.  This holds for
+ * the two attention entry points below as well.
  */
 int mi355q_paged_attention(void* out, float* exp_sums, float* max_logits, void* tmp_out,
                            const void* query, int64_t q_stride, const void* key_cache,
@@ -393,7 +401,11 @@ int mi355q_decode_attention_fused(
 /* Sampler inner loop                                                  */
 /* ------------------------------------------------------------------ */
 /* ids[b] = first index of max(float(logits[b, :])).  Replaces
- * logits.float().argmax(-1) (vllm/v1/sample/sampler.py:96,240-241). */
+ * logits.float().argmax(-1) (vllm/v1/sample/sampler.py:96,240-241).
+ * Rows of 16384 values or more are cut into segments whose results meet in one 64-bit
+ * slot per row (library-owned device memory, zero between launches, up to 1024 rows; more
+ * rows, unaligned rows or MI355Q_ARGMAX_NARROW=1 take the single-workgroup kernel).  Argmax
+ * launches that overlap on one GPU would share the slots: keep them on one stream. */
 int mi355q_argmax(const void* logits, int64_t row_stride, int64_t* ids, int num_rows, int vocab,
                   int dtype, mi355q_stream_t stream);
 /* In place; masks are bool (1 byte) [B, V]; penalties [B] in logits dtype.
