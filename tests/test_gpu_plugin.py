@@ -78,6 +78,35 @@ def test_gptq_linear_methods_match_oracle():
     np.testing.assert_allclose(f32(to_bits(fused)), f32(ref), rtol=1e-2, atol=1e-2)
 
 
+def test_auto_round_checkpoint_runs_on_the_gptq_route():
+    """An AutoRound (`quant_method: "auto-round"`, auto_gptq packing) layer: INCConfig -> INCLinearMethod
+    -> the GPTQ method and kernel; same numbers as the oracle, a listed 16-bit layer stays a plain linear."""
+    from mi355q.plugin import INCConfig, INCLinearMethod
+    from mi355q.plugin.linear import UnquantizedLinearMethod
+    rng = np.random.default_rng(3)
+    hidden, inter, G, T = 512, 1536, 128, 3
+    cfg = INCConfig.from_config({"quant_method": "auto-round", "bits": 4, "group_size": G, "sym": True,
+                                 "packing_format": "auto_round:auto_gptq",
+                                 "extra_config": {"model.layers.0.mlp.gate": {"bits": 16, "data_type": "float"}}})
+    with torch.device(DEV):
+        down = RowParallelLinear(inter, hidden, bias=False, params_dtype=torch.bfloat16, quant_config=cfg,
+                                 prefix="model.layers.0.mlp.down_proj", return_bias=False)
+        gate = RowParallelLinear(hidden, 64, bias=False, params_dtype=torch.bfloat16, quant_config=cfg,
+                                 prefix="model.layers.0.mlp.gate", return_bias=False)
+    assert isinstance(down.quant_method, INCLinearMethod)
+    assert isinstance(gate.quant_method, UnquantizedLinearMethod)
+    q = rng.integers(0, 16, size=(inter, hidden), dtype=np.int32)
+    s = orc.f32_to_h16((0.02 * rng.random((inter // G, hidden)) + 0.005).astype(np.float32))
+    down.weight_loader(down.qweight, torch.from_numpy(orc.gptq_pack(q)))
+    down.weight_loader(down.scales, to_dev(s).cpu())
+    down.process_weights_after_loading()
+    x = orc.f32_to_h16(rng.standard_normal((T, inter)).astype(np.float32))
+    ref = orc.w4a16_gemm(x, orc.gptq_pack(q), s, None, None, G=G)
+    got = down(to_dev(x))
+    np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=1e-2)
+    assert (to_bits(got) == ref).mean() > 0.98
+
+
 def test_awq_linear_method_matches_oracle():
     rng = np.random.default_rng(1)
     K, N, G, T = 512, 768, 128, 3

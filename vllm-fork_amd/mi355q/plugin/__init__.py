@@ -9,6 +9,7 @@ same semantics) are used, which is what the tests and the bundled Llama runner d
 from .awq import AutoAWQConfig, AutoAWQLinearMethod
 from .fp8 import Fp8Config, Fp8LinearMethod
 from .gptq import AutoGPTQConfig, AutoGPTQLinearMethod
+from .inc import INCConfig, INCLayerConfig, INCLinearMethod, INCWna16Scheme, resolve_scheme
 from .moe import FusedMoE, MoeWNA16Config, MoeWNA16Method, fused_experts, fused_topk
 from .mp_kernel import (MI355XW4A16LinearKernel, MPLinearKernel, MPLinearLayerConfig, choose_mp_linear_kernel,
                         register_linear_kernel)
