@@ -107,6 +107,52 @@ def test_auto_round_checkpoint_runs_on_the_gptq_route():
     assert (to_bits(got) == ref).mean() > 0.98
 
 
+def test_gptq_act_order_checkpoint():
+    """desc_act=True: row k of the checkpoint belongs to group g_idx[k].  Reference semantics
+    (q_gemm.cu:189-228: weights gathered through the sorted permutation, scales by group):
+    W[k, n] = (q[k, n] - 8) * s[g_idx[k], n]; checked against that definition computed directly."""
+    rng = np.random.default_rng(8)
+    hidden, out, G, T = 1024, 512, 128, 4
+    cfg = AutoGPTQConfig.from_config({"bits": 4, "group_size": G, "desc_act": True, "sym": True})
+    with torch.device(DEV):
+        lin = MergedColumnParallelLinear(hidden, [out // 2, out // 2], bias=False, params_dtype=torch.bfloat16,
+                                         quant_config=cfg, prefix="mlp.gate_up_proj", return_bias=False)
+    q = rng.integers(0, 16, size=(hidden, out), dtype=np.int32)
+    s = orc.f32_to_h16((0.02 * rng.random((hidden // G, out)) + 0.005).astype(np.float32))
+    g_idx = rng.permutation(np.arange(hidden) // G).astype(np.int32)
+    half = out // 2
+    for i in range(2):
+        lin.weight_loader(lin.qweight, torch.from_numpy(orc.gptq_pack(q[:, i * half:(i + 1) * half])), i)
+        lin.weight_loader(lin.scales, to_dev(s[:, i * half:(i + 1) * half]).cpu(), i)
+    lin.weight_loader(lin.g_idx, torch.from_numpy(g_idx))
+    lin.process_weights_after_loading()
+    assert lin.mi355q_perm is not None
+    x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    W = (q - 8).astype(np.float64) * f32(s)[g_idx].astype(np.float64)
+    ref = f32(x).astype(np.float64) @ W
+    got = f32(to_bits(lin(to_dev(x))))
+    np.testing.assert_allclose(got, ref, rtol=1e-2, atol=2e-2)
+    # the fused-prologue entry points of the kernel object serve reordered layers too
+    k = lin.quant_method.kernel
+    res = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    nw = orc.f32_to_h16((1 + 0.1 * rng.standard_normal(hidden)).astype(np.float32))
+    y, r2 = k.apply_weights_add_rms_norm(lin, to_dev(x), to_dev(res), to_dev(nw), 1e-5)
+    xn, rn = orc.fused_add_rms_norm(x, res, nw, 1e-5)
+    assert np.array_equal(to_bits(r2), rn)
+    np.testing.assert_allclose(f32(to_bits(y)), f32(xn).astype(np.float64) @ W, rtol=1e-2, atol=2e-2)
+    # a trivial g_idx (checkpoint written without reordering) takes the plain route
+    with torch.device(DEV):
+        lin2 = RowParallelLinear(hidden, out, bias=False, params_dtype=torch.bfloat16, quant_config=cfg,
+                                 prefix="mlp.down_proj", return_bias=False)
+    lin2.weight_loader(lin2.qweight, torch.from_numpy(orc.gptq_pack(q)))
+    lin2.weight_loader(lin2.scales, to_dev(s).cpu())
+    lin2.weight_loader(lin2.g_idx, torch.from_numpy((np.arange(hidden) // G).astype(np.int32)))
+    lin2.process_weights_after_loading()
+    assert lin2.mi355q_perm is None
+    ref2 = orc.w4a16_gemm(x, orc.gptq_pack(q), s, None, None, G=G)
+    assert (to_bits(lin2(to_dev(x))) == ref2).mean() > 0.98
+
+
 def test_awq_linear_method_matches_oracle():
     rng = np.random.default_rng(1)
     K, N, G, T = 512, 768, 128, 3

@@ -147,7 +147,10 @@ def _kcfg(**kw):
 def test_kernel_selection_and_reasons(monkeypatch):
     assert choose_mp_linear_kernel(_kcfg()) is MI355XW4A16LinearKernel
     assert choose_mp_linear_kernel(_kcfg(weight_type=scalar_types.uint4, zero_points=True)) is MI355XW4A16LinearKernel
-    for bad, why in ((dict(has_g_idx=True), "g_idx"), (dict(act_type=torch.float32), "float16/bfloat16"),
+    # activation reordering is served when the whole of K is on the rank, refused when K is sharded
+    assert choose_mp_linear_kernel(_kcfg(has_g_idx=True)) is MI355XW4A16LinearKernel
+    for bad, why in ((dict(has_g_idx=True, partition_weight_shape=(2048, 6144)), "g_idx"),
+                     (dict(act_type=torch.float32), "float16/bfloat16"),
                      (dict(weight_type=scalar_types.uint8b128), "not supported"),
                      (dict(partition_weight_shape=(4096, 100)), "multiple of 64"),
                      (dict(group_size=100), "not divisible"), (dict(weight_type=scalar_types.uint4), "zero points")):
@@ -461,3 +464,27 @@ def test_moe_config_and_loader_conversions(tp):
         back = np.empty((w.K, w.N), dtype=np.int32)
         _lib.check(_lib.lib().mi355q_w4a16_unpack_host(w.packed.data_ptr(), back.ctypes.data, w.K, w.N, w.tile))
         assert np.array_equal(back, w2[1][rank * half:(rank + 1) * half])
+
+
+def test_act_order_row_permutation_helpers():
+    """GPTQ desc_act: rows sorted by group (stable), packed rows moved nibble by nibble."""
+    from mi355q.plugin.mp_kernel import _act_order_perm, _permute_packed_rows
+    rng = np.random.default_rng(4)
+    K, N, G = 256, 16, 64
+    assert _act_order_perm(None, K, G) is None
+    assert _act_order_perm(torch.empty(0, dtype=torch.int32), K, G) is None
+    assert _act_order_perm(torch.zeros(K, dtype=torch.int32), K, G) is None          # untouched placeholder
+    assert _act_order_perm(torch.arange(K, dtype=torch.int32) // G, K, G) is None     # already in group order
+    g_idx = rng.permutation(np.arange(K) // G).astype(np.int32)
+    perm = _act_order_perm(torch.from_numpy(g_idx), K, G)
+    assert np.array_equal(g_idx[perm.numpy()], np.arange(K) // G)
+    assert np.array_equal(perm.numpy(), np.argsort(g_idx, kind="stable"))
+    with pytest.raises(ValueError, match="exactly group_size rows"):
+        bad = g_idx.copy()
+        bad[bad == 1] = 0
+        _act_order_perm(torch.from_numpy(bad), K, G)
+    with pytest.raises(ValueError, match="entries for"):
+        _act_order_perm(torch.zeros(K - 8, dtype=torch.int32), K, G)
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    got = _permute_packed_rows(torch.from_numpy(orc.gptq_pack(q)), perm)
+    assert np.array_equal(got.numpy(), orc.gptq_pack(q[perm.numpy()]))

@@ -260,11 +260,12 @@ def gptq_gemm(a, b_q_weight: PackedW4, b_gptq_qzeros, b_gptq_scales, b_g_idx, us
               use_v2_format: bool, bit: int) -> torch.Tensor:
     """Signature of ops.gptq_gemm (vllm/_custom_ops.py:558-577).  b_q_weight is the
     repacked weight (the reference passes the gptq_shuffle'd tensor here); zeros and scales
-    travel inside it, g_idx must be empty (act-order is not supported yet)."""
+    travel inside it; g_idx must be empty here -- checkpoints with activation reordering are served
+    one level up (MI355XW4A16LinearKernel sorts the rows at load time and gathers the inputs)."""
     if bit != 4:
         raise RuntimeError(f"gptq_gemm: {bit}-bit weights are not supported")
     if b_g_idx is not None and b_g_idx.numel() > 0:
-        raise RuntimeError("gptq_gemm: act-order (g_idx) is not supported")
+        raise RuntimeError("gptq_gemm: pass activation-reordered layers through MI355XW4A16LinearKernel (g_idx must be empty here)")
     return w4a16_gemm(a, b_q_weight)
 
 

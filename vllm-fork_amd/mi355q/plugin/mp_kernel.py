@@ -111,8 +111,10 @@ class MI355XW4A16LinearKernel(MPLinearKernel):
             return False, f"Quant type {c.weight_type} not supported; supported: {list(cls.SUPPORTED_QUANT_TYPES)}"
         if c.act_type not in (torch.float16, torch.bfloat16):
             return False, "Only float16/bfloat16 activations are supported"
-        if c.has_g_idx:
-            return False, "Activation reordering (g_idx) is not supported"
+        if c.has_g_idx and c.partition_weight_shape[0] != c.full_weight_shape[0]:
+            # rows of one scale group are then spread over the ranks: the sorted order that makes
+            # groups contiguous needs the whole of K on one rank
+            return False, "Activation reordering (g_idx) with the input dimension sharded is not supported"
         if c.weight_type == scalar_types.uint4 and not c.zero_points:
             return False, "uint4 weights need zero points (symmetric checkpoints use uint4b8)"
         K, N = c.partition_weight_shape
@@ -160,6 +162,19 @@ class MI355XW4A16LinearKernel(MPLinearKernel):
             if tuple(z.shape) != (K // G, N // 8):
                 raise ValueError(f"{self.w_zp_name}: shape {tuple(w_zp.shape)} != ({K // G}, {N // 8})")
             zp_mode = self.zp_mode if self.zp_mode is not None else _lib.ZP_NSEQ
+        # Activation order (GPTQ desc_act): row k belongs to group g_idx[k].  Sorting the rows by
+        # group makes groups contiguous again (what gptq_shuffle + the b_q_perm gather do in the
+        # reference, q_gemm.cu:224-228,1857-1868); the same permutation is applied to the input
+        # features at run time.
+        layer.mi355q_perm = None
+        if c.has_g_idx:
+            w_g = getattr(layer, self.w_gidx_name) if self.w_gidx_name else None
+            perm = _act_order_perm(None if w_g is None else w_g.data, K, G)
+            if perm is not None:
+                if layout != _lib.W_GPTQ:
+                    raise ValueError("activation reordering is defined for weights packed along K (GPTQ layout)")
+                q = _permute_packed_rows(q.contiguous(), perm)
+                layer.mi355q_perm = perm
         w = ops.w4a16_repack(q.contiguous(), s.contiguous().to(c.act_type), None if z is None else z.contiguous(),
                              G, layout, zp_mode)
         _set_param(layer, self.w_q_name, w.packed)
@@ -174,15 +189,61 @@ class MI355XW4A16LinearKernel(MPLinearKernel):
 
     # -- run time ----------------------------------------------------------
     def apply_weights(self, layer, x, bias=None):
+        perm = getattr(layer, "mi355q_perm", None)
+        if perm is not None:
+            x = x.index_select(-1, perm)
         return ops.w4a16_gemm(x, layer.mi355q_weight, bias=bias)
 
     def apply_weights_silu_mul(self, layer, x, bias=None):
         """x = [.., 2K] gate_up output; SiluAndMul runs in the GEMM prologue."""
+        if getattr(layer, "mi355q_perm", None) is not None:   # reordered inputs: activation first, then gather
+            act = torch.empty(x.shape[:-1] + (x.shape[-1] // 2,), dtype=x.dtype, device=x.device)
+            ops.silu_and_mul(act, x)
+            return self.apply_weights(layer, act, bias)
         return ops.w4a16_gemm(x, layer.mi355q_weight, bias=bias, fuse_silu_mul=True)
 
     def apply_weights_add_rms_norm(self, layer, x, residual, norm_weight, epsilon, bias=None):
         """fused_add_rms_norm(x, residual) then the GEMM; returns (output, new residual)."""
+        if getattr(layer, "mi355q_perm", None) is not None:
+            if residual is None:
+                residual = x
+                normed = torch.empty_like(x)
+                ops.rms_norm(normed, x, norm_weight, epsilon)
+            else:
+                normed, residual = x.clone(), residual.clone()
+                ops.fused_add_rms_norm(normed, residual, norm_weight, epsilon)
+            return self.apply_weights(layer, normed, bias), residual
         return ops.w4a16_gemm_add_rms_norm(x, residual, norm_weight, epsilon, layer.mi355q_weight, bias=bias)
+
+
+def _act_order_perm(g_idx: torch.Tensor | None, K: int, G: int) -> torch.Tensor | None:
+    """Row order that sorts a GPTQ g_idx by group (stable), or None when the rows already are in
+    group order (checkpoints written without activation reordering carry a trivial or empty g_idx)."""
+    if g_idx is None or g_idx.numel() == 0:
+        return None
+    if g_idx.numel() != K:
+        raise ValueError(f"g_idx has {g_idx.numel()} entries for {K} input features")
+    g = g_idx.to(torch.int64)
+    want = torch.arange(K, device=g.device, dtype=torch.int64) // G
+    if torch.equal(g, want) or not bool(g.any()):
+        return None
+    perm = torch.argsort(g, stable=True)
+    if not torch.equal(g[perm], want):
+        raise ValueError("g_idx does not assign exactly group_size rows to every group")
+    return perm
+
+
+def _permute_packed_rows(qweight: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    """qweight int32 [K/8, N] (8 consecutive k per word, nibble i at bit 4 i) with its K rows
+    taken in the order `perm`."""
+    K8, N = qweight.shape
+    shifts = torch.arange(0, 32, 4, device=qweight.device, dtype=torch.int32)
+    rows = ((qweight[:, None, :] >> shifts[None, :, None]) & 0xF).reshape(K8 * 8, N)
+    rows = rows.index_select(0, perm.to(qweight.device)).reshape(K8, 8, N)
+    out = torch.zeros((K8, N), dtype=torch.int32, device=qweight.device)
+    for i in range(8):
+        out |= rows[:, i, :] << (4 * i)
+    return out
 
 
 # platform name -> ordered kernel classes.  "rocm" is the only platform this package serves.
