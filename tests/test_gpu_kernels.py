@@ -880,6 +880,43 @@ def test_moe_expert_map_and_sum():
     assert torch.equal(s, y.float().sum(1).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("awq", [False, True])
+def test_moe_decode_slots_on_the_burst_kernel(awq):
+    """Expert layers wide enough to occupy the chip (>= 128 strips per slot) take the one-workgroup-
+    per-strip decode kernel with the expert indirection: same bar as the dense GEMV, including slots
+    whose expert is held elsewhere (zero rows) and zero points."""
+    import moe_ref
+    from mi355q.plugin import fused_experts
+    rng = np.random.default_rng(31 + awq)
+    E, H, I, G, T, topk = 4, 1024, 2048, 128, 2, 2
+    def mk(n, k):
+        z = rng.integers(0, 256, size=(E, n // 2, k // G), dtype=np.uint8) if awq else None
+        return (rng.integers(0, 256, size=(E, n, k // 2), dtype=np.uint8),
+                orc.f32_to_h16((0.02 * rng.random((E, n, k // G)) + 0.005).astype(np.float32)), z)
+    w1, w2 = mk(2 * I, H), mk(H, I)
+    emap = np.array([0, 1, -1, 2], dtype=np.int32)
+    local = [0, 1, 3]
+    def dev(w):
+        return ops.moe_w4a16_repack(torch.from_numpy(w[0][local]).to(DEV), to_dev(w[1][local]),
+                                    None if w[2] is None else torch.from_numpy(w[2][local]).to(DEV), G)
+    d13, d2 = dev(w1), dev(w2)
+    assert d13.N // d13.tile >= 128 and d2.N // d2.tile * T * topk >= 128
+    a = orc.f32_to_h16((0.5 * rng.standard_normal((T, H))).astype(np.float32))
+    ids = np.array([[0, 2], [3, 1]], dtype=np.int32)
+    tw = rng.random((T, topk)).astype(np.float32)
+    out = fused_experts(to_dev(a), d13, d2, torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV),
+                        torch.from_numpy(emap).to(DEV))
+    sub = lambda w: (w[0][local], w[1][local], None if w[2] is None else w[2][local])
+    ref = moe_ref.moe(a, sub(w1), sub(w2), tw, ids, G, expert_map=emap)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=5e-3)
+    # the slot rows themselves: expert GEMV against the oracle, zero row for the absent expert
+    lids = torch.from_numpy(emap[ids.reshape(-1)]).to(DEV)
+    h = ops.moe_w4a16_gemm(to_dev(a), d13, lids, topk)
+    assert not h[1].any()
+    r0 = moe_ref.expert_gemm(a[:1], w1[0][0], w1[1][0], None if w1[2] is None else w1[2][0], G)
+    assert (to_bits(h[:1]) == r0).mean() > 0.98
+
+
 # ---------------------------------------------------------------------------
 # gate_up projection with SiluAndMul in its epilogue (pair_halves layout)
 # ---------------------------------------------------------------------------

@@ -702,6 +702,12 @@ struct BurstParams {
   int nw;       // waves per workgroup; chunks == nw * CPW * bursts
   int bursts;
   int epi_silu;  // 1: channels are (gate, up) pairs; write silu(gate) * up, N / 2 values per row
+  // mixture of experts (rows_pp == 1): output row z is one (token, selected expert) slot; its
+  // weights are those of expert_ids[z] (negative: the row is zero-filled), its input row z / x_row_div
+  const int* expert_ids;
+  int x_row_div;
+  long long wp_estride;   // u32x4 units between experts
+  long long sc_estride;   // 16-bit elements between experts (scales and zc)
   unsigned long long* stamps;  // diagnostics: 4 x 100 MHz timestamps per workgroup, or null
 };
 
@@ -728,6 +734,22 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
   uint16_t* act = zc_l + (HAS_ZC ? (size_t)groups * SW : 0);                   // [rows_pp][astride]
 
   const u32x4* wstrip = p.wp + (size_t)strip * p.chunks * NS * 64 + lane;
+  const uint16_t* scales_e = p.scales;
+  const uint16_t* zc_e = p.zc;
+  int xrow0 = row0;
+  if (p.expert_ids) {
+    const int e = p.expert_ids[row0];
+    if (e < 0) {   // expert held by another rank: the slot contributes nothing
+      const int ncols = p.epi_silu ? SW / 2 : SW;
+      uint16_t* o = p.out + (size_t)row0 * (p.epi_silu ? p.N >> 1 : p.N) + (size_t)strip * ncols;
+      for (int i = threadIdx.x; i < ncols; i += nthreads) o[i] = 0;
+      return;
+    }
+    wstrip += (size_t)e * p.wp_estride;
+    scales_e += (size_t)e * p.sc_estride;
+    if (HAS_ZC) zc_e += (size_t)e * p.sc_estride;
+    xrow0 = row0 / p.x_row_div;
+  }
   const int cpw_total = CPW * p.bursts;
   const int cfirst = wave * cpw_total;  // this wave's chunks: [cfirst, cfirst + cpw_total)
 
@@ -737,7 +759,7 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
   u32x4 xa[BURST_XV], xb[BURST_XV], xw[BURST_XV];
   const bool single = Mt == 1 && vecs_row <= BURST_XV * nthreads;
   if (single) {
-    const uint16_t* xr = p.x + (size_t)row0 * p.ldx;
+    const uint16_t* xr = p.x + (size_t)xrow0 * p.ldx;
 #pragma unroll
     for (int i = 0; i < BURST_XV; i++) {
       const int v = threadIdx.x + i * nthreads;
@@ -762,8 +784,8 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
     const int d = threadIdx.x + i * nthreads;
     if (d < sdw) {   // strip-major: the strip's groups x SW scales are contiguous
       const size_t off = (size_t)strip * sdw * 2 + 2 * (size_t)d;
-      s_reg[i] = *reinterpret_cast<const uint32_t*>(p.scales + off);
-      if constexpr (HAS_ZC) z_reg[i] = *reinterpret_cast<const uint32_t*>(p.zc + off);
+      s_reg[i] = *reinterpret_cast<const uint32_t*>(scales_e + off);
+      if constexpr (HAS_ZC) z_reg[i] = *reinterpret_cast<const uint32_t*>(zc_e + off);
     }
   }
 
@@ -787,8 +809,8 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
   }
   for (int d = threadIdx.x + SR * nthreads; d < sdw; d += nthreads) {
     const size_t off = (size_t)strip * sdw * 2 + 2 * (size_t)d;
-    reinterpret_cast<uint32_t*>(sc_l)[d] = *reinterpret_cast<const uint32_t*>(p.scales + off);
-    if constexpr (HAS_ZC) reinterpret_cast<uint32_t*>(zc_l)[d] = *reinterpret_cast<const uint32_t*>(p.zc + off);
+    reinterpret_cast<uint32_t*>(sc_l)[d] = *reinterpret_cast<const uint32_t*>(scales_e + off);
+    if constexpr (HAS_ZC) reinterpret_cast<uint32_t*>(zc_l)[d] = *reinterpret_cast<const uint32_t*>(zc_e + off);
   }
 
   if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
@@ -865,7 +887,7 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
           for (int m = 0; m < 4; m++) {
             if (m < nm) {
               const size_t off = (size_t)(row0 + mb + m);
-              const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + off * p.ldx + 8 * v);
+              const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + (size_t)(xrow0 + mb + m) * p.ldx + 8 * v);
               u32x4 rv = u32x4{0u, 0u, 0u, 0u};
               if (p.res_in) rv = *reinterpret_cast<const u32x4*>(p.res_in + off * p.K + 8 * v);
 #pragma unroll
@@ -898,7 +920,7 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
       for (int idx = threadIdx.x; idx < nm * vecs_row; idx += nthreads) {
         const int m = idx / vecs_row, v = idx - m * vecs_row;
         const size_t off = (size_t)(row0 + mb + m);
-        const uint16_t* src = p.x + off * p.ldx + 8 * v;
+        const uint16_t* src = p.x + (size_t)(xrow0 + mb + m) * p.ldx + 8 * v;
         const u32x4 xv = *reinterpret_cast<const u32x4*>(src);
         u32x4 o = xv;
         if constexpr (PRO == PRO_SILU) {
@@ -1718,13 +1740,24 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
     }
   }
   // decode path: one burst workgroup per strip whenever the strips alone occupy the chip
-  if (!moe) {
+  {
     const int ns = sw / 16;
-    const BurstPlan bp = plan_burst(M, K, G, ns, zc != nullptr);
+    BurstPlan bp = plan_burst(moe ? 1 : M, K, G, ns, zc != nullptr);
     const char* nb = getenv("MI355Q_NO_BURST");
-    const bool want_split = !epi_silu && (split_k > 1 || (N / sw) * ((M + 15) / 16) < 128);
+    const long blocks = moe ? (long)(N / sw) * M : (long)(N / sw) * ((M + 15) / 16);
+    const bool want_split = !epi_silu && (split_k > 1 || blocks < 128);
+    if (moe) {
+      bp.ok = bp.ok && pro != PRO_ADDNORM && bias == nullptr && moe->expert_ids && moe->x_row_div >= 1;
+      bp.rows_pp = 1;
+    }
     if (bp.ok && !(nb && atoi(nb)) && (!legacy_tile(sw) || !want_split)) {
       BurstParams b;
+      b.expert_ids = nullptr; b.x_row_div = 1; b.wp_estride = 0; b.sc_estride = 0;
+      if (moe) {
+        b.expert_ids = moe->expert_ids; b.x_row_div = moe->x_row_div;
+        b.wp_estride = (long long)K * N / 32;    // K*N/2 bytes per expert
+        b.sc_estride = (long long)(K / G) * N;
+      }
       b.x = (const uint16_t*)x; b.ldx = ldx; b.wp = (const u32x4*)packed;
       b.scales = (const uint16_t*)scales; b.zc = (const uint16_t*)zc; b.bias = (const uint16_t*)bias;
       b.out = (uint16_t*)c;

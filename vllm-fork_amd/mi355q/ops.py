@@ -311,7 +311,7 @@ def moe_w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.
         raise RuntimeError(f"moe scales shape {tuple(scales.shape)} != ({E}, {N}, {K // G})")
     if qzeros is not None and (qzeros.dtype != torch.uint8 or qzeros.shape != (E, N // 2, K // G)):
         raise RuntimeError(f"moe qzeros must be uint8 [{E}, {N // 2}, {K // G}]")
-    tile = _lib.lib().mi355q_w4a16_choose_tile(K, N, G)
+    tile = _lib.lib().mi355q_w4a16_choose_strip(K, N, G)
     packed = torch.empty((E, K * N // 8), dtype=torch.int32, device=qweight.device)
     sc = torch.empty((E, N // tile, K // G, tile), dtype=scales.dtype, device=qweight.device)
     zc = None if qzeros is None else torch.empty((E, N // tile, K // G, tile), dtype=scales.dtype, device=qweight.device)
