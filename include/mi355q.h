@@ -228,6 +228,10 @@ int mi355q_topk_softmax(float* topk_weights, int32_t* topk_ids, const void* gati
  * Expert GEMM for decode: output row r ("slot" = one (token, selected expert) pair) is
  *   c[r, :] = x[r / x_row_div, :] * dequant(W[expert_ids[r]])      (fuse_silu_mul = 0)
  *   c[r, :] = (silu(x[r, :K]) * x[r, K:2K]) * dequant(W[expert_ids[r]])   (fuse_silu_mul = 1)
+ *   c[r, :N/2] = silu(y[2i]) * y[2i+1], y = x[r / x_row_div, :] * dequant(W[...])   (fuse_silu_mul = 2:
+ *                experts repacked with MI355Q_W_PAIR_HALVES, SiluAndMul in the epilogue as in
+ *                mi355q_w4a16_gate_up_silu; needs a layer the one-workgroup-per-strip kernel serves,
+ *                mi355q_w4a16_gate_up_silu_supported)
  * with every expert's weight repacked by mi355q_w4a16_repack (same tile width) and stored
  * back to back: packed [E][K*N/2 bytes], scales [E][K/G][N], zc [E][K/G][N] or NULL.
  * expert_ids[r] < 0 (expert held by another rank) zero-fills the row.  No token sorting /

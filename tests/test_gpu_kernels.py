@@ -829,8 +829,8 @@ def _moe_case(g, tag):
 
 def test_moe_golden_and_oracle(golden, monkeypatch):
     """The expert path against the reference's expected outputs (tests/kernels/moe/test_moe.py:698,
-    atol 2e-2) and, tightly, against the oracle restatement with fp32 weights; both the per-slot
-    kernel route and the grouped dense route for many tokens."""
+    atol 2e-2) and, tightly, against the oracle restatement with fp32 weights; the per-slot
+    kernel route, the every-expert-over-all-tokens route and the grouped dense route for many tokens."""
     import moe_ref
     from mi355q.plugin import fused_experts, fused_topk, moe as moe_mod
     g = golden("moe")
@@ -844,14 +844,14 @@ def test_moe_golden_and_oracle(golden, monkeypatch):
         np.testing.assert_allclose(tw.cpu().numpy(), rw, rtol=1e-5)
         ref = f32(g[tag + "_ref"])
         exact = f32(moe_ref.moe(g[tag + "_a"], w1, w2, rw, rids, G))
-        for limit in (1 << 30, 0):    # slot route, grouped dense route
-            monkeypatch.setattr(moe_mod, "SLOT_ROUTE_MAX", limit)
+        for route in ("slots", "all_experts", "grouped", None):
+            monkeypatch.setattr(moe_mod, "FORCE_ROUTE", route)
             out = f32(to_bits(fused_experts(a, d13, d2, tw, ids)))
             np.testing.assert_allclose(out, ref, rtol=0, atol=2e-2, err_msg=tag)
             np.testing.assert_allclose(out, exact, rtol=1e-2, atol=2e-3, err_msg=tag)
 
 
-def test_moe_expert_map_and_sum():
+def test_moe_expert_map_and_sum(monkeypatch):
     """Slots whose expert lives on another rank contribute nothing; moe_sum without weights is a
     plain fp32 sum."""
     import moe_ref
@@ -869,19 +869,22 @@ def test_moe_expert_map_and_sum():
     a = orc.f32_to_h16(rng.standard_normal((T, H)).astype(np.float32))
     ids = np.array([[0, 1], [3, 2], [1, 3]], dtype=np.int32)
     tw = rng.random((T, topk)).astype(np.float32)
-    out = fused_experts(to_dev(a), d13, d2, torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV),
-                        torch.from_numpy(emap).to(DEV))
+    from mi355q.plugin import moe as moe_mod
     ref = moe_ref.moe(a, (w1[0][local], w1[1][local], None), (w2[0][local], w2[1][local], None), tw, ids, G,
                       expert_map=emap)
-    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=2e-3)
+    for route in ("slots", "all_experts", None):
+        monkeypatch.setattr(moe_mod, "FORCE_ROUTE", route)
+        out = fused_experts(to_dev(a), d13, d2, torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV),
+                            torch.from_numpy(emap).to(DEV))
+        np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=2e-3, err_msg=str(route))
     y = torch.randn((T, topk, H), device=DEV).to(torch.bfloat16)
     s = torch.empty((T, H), dtype=torch.bfloat16, device=DEV)
     ops.moe_sum(y, s)
     assert torch.equal(s, y.float().sum(1).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("awq", [False, True])
-def test_moe_decode_slots_on_the_burst_kernel(awq):
+@pytest.mark.parametrize("awq,pair", [(False, False), (True, False), (False, True), (True, True)])
+def test_moe_decode_slots_on_the_burst_kernel(awq, pair, monkeypatch):
     """Expert layers wide enough to occupy the chip (>= 128 strips per slot) take the one-workgroup-
     per-strip decode kernel with the expert indirection: same bar as the dense GEMV, including slots
     whose expert is held elsewhere (zero rows) and zero points."""
@@ -896,25 +899,40 @@ def test_moe_decode_slots_on_the_burst_kernel(awq):
     w1, w2 = mk(2 * I, H), mk(H, I)
     emap = np.array([0, 1, -1, 2], dtype=np.int32)
     local = [0, 1, 3]
-    def dev(w):
+    def dev(w, pair_halves=False):
         return ops.moe_w4a16_repack(torch.from_numpy(w[0][local]).to(DEV), to_dev(w[1][local]),
-                                    None if w[2] is None else torch.from_numpy(w[2][local]).to(DEV), G)
-    d13, d2 = dev(w1), dev(w2)
+                                    None if w[2] is None else torch.from_numpy(w[2][local]).to(DEV), G,
+                                    pair_halves=pair_halves)
+    d13, d2 = dev(w1, pair), dev(w2)
+    assert d13.pair_halves == pair
     assert d13.N // d13.tile >= 128 and d2.N // d2.tile * T * topk >= 128
     a = orc.f32_to_h16((0.5 * rng.standard_normal((T, H))).astype(np.float32))
     ids = np.array([[0, 2], [3, 1]], dtype=np.int32)
     tw = rng.random((T, topk)).astype(np.float32)
-    out = fused_experts(to_dev(a), d13, d2, torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV),
-                        torch.from_numpy(emap).to(DEV))
+    from mi355q.plugin import moe as moe_mod
     sub = lambda w: (w[0][local], w[1][local], None if w[2] is None else w[2][local])
     ref = moe_ref.moe(a, sub(w1), sub(w2), tw, ids, G, expert_map=emap)
-    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=5e-3)
+    ref_rw = moe_ref.moe(a, sub(w1), sub(w2), tw, ids, G, expert_map=emap, round_weight=True)
+    scale_mag = max(1.0, float(np.abs(f32(ref)).max()) / 4)   # zero points un-centre the weights: larger outputs
+    for route in ("slots", "all_experts", "grouped"):
+        monkeypatch.setattr(moe_mod, "FORCE_ROUTE", route)
+        out = fused_experts(to_dev(a), d13, d2, torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV),
+                            torch.from_numpy(emap).to(DEV))
+        # the grouped route multiplies with weights rounded to 16 bits (the reference's many-token
+        # arithmetic): compared with the oracle in that mode
+        want = ref_rw if route == "grouped" else ref
+        np.testing.assert_allclose(f32(to_bits(out)), f32(want), rtol=1e-2, atol=5e-3 * scale_mag, err_msg=route)
     # the slot rows themselves: expert GEMV against the oracle, zero row for the absent expert
     lids = torch.from_numpy(emap[ids.reshape(-1)]).to(DEV)
-    h = ops.moe_w4a16_gemm(to_dev(a), d13, lids, topk)
-    assert not h[1].any()
     r0 = moe_ref.expert_gemm(a[:1], w1[0][0], w1[1][0], None if w1[2] is None else w1[2][0], G)
-    assert (to_bits(h[:1]) == r0).mean() > 0.98
+    if pair:
+        h = ops.moe_w4a16_gemm(to_dev(a), d13, lids, topk, silu_pairs=True)
+        assert h.shape == (T * topk, I) and not h[1].any()
+        assert (to_bits(h[:1]) == orc.silu_and_mul(r0)).mean() > 0.97
+    else:
+        h = ops.moe_w4a16_gemm(to_dev(a), d13, lids, topk)
+        assert not h[1].any()
+        assert (to_bits(h[:1]) == r0).mean() > 0.98
 
 
 # ---------------------------------------------------------------------------

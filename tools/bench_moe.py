@@ -14,7 +14,7 @@ for _ in range(3):    # 3 layers x 8 experts x 88 MB: nothing stays cache-reside
     s13 = (torch.rand((E, 2 * I, H // G), device=dev, generator=g) * 0.02).to(torch.bfloat16)
     qw2 = torch.randint(0, 256, (E, H, I // 2), dtype=torch.uint8, device=dev, generator=g)
     s2 = (torch.rand((E, H, I // G), device=dev, generator=g) * 0.02).to(torch.bfloat16)
-    layers.append((ops.moe_w4a16_repack(qw13, s13, None, G), ops.moe_w4a16_repack(qw2, s2, None, G)))
+    layers.append((ops.moe_w4a16_repack(qw13, s13, None, G, pair_halves=True), ops.moe_w4a16_repack(qw2, s2, None, G)))
     del qw13, qw2
 for T in [int(a) for a in sys.argv[1:]] or [1, 4]:
     x = (torch.randn((T, H), device=dev, generator=g) * 0.25).to(torch.bfloat16)

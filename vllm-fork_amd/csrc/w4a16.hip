@@ -1961,8 +1961,9 @@ extern "C" int mi355q_moe_w4a16_gemm(const void* x, int ldx, int x_row_div, cons
                                      int tile, int act_dtype, int fuse_silu_mul,
                                      mi355q_stream_t stream) {
   MoeArgs moe{expert_ids, x_row_div, num_experts};
+  MI355Q_REQUIRE(fuse_silu_mul >= 0 && fuse_silu_mul <= 2, "moe_w4a16_gemm: fuse_silu_mul must be 0, 1 or 2");
   return gemm_impl(x, ldx, packed, scales, zc, nullptr, c, slots, N, K, G, tile, act_dtype, nullptr, 0, 1,
-                   (hipStream_t)stream, fuse_silu_mul ? PRO_SILU : PRO_NONE, nullptr, &moe);
+                   (hipStream_t)stream, fuse_silu_mul == 1 ? PRO_SILU : PRO_NONE, nullptr, &moe, fuse_silu_mul == 2);
 }
 
 // Strip width for decode: strips of 16 NS channels such that the layer gives about one

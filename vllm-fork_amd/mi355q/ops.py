@@ -126,7 +126,7 @@ def _workspace(dev, nbytes: int) -> torch.Tensor:
 
 
 def w4a16_gemm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, split_k: int = 0,
-               fuse_silu_mul: bool = False) -> torch.Tensor:
+               fuse_silu_mul: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
     """x[..., K] @ dequant(w)[K, N] (+ bias).  Stands in for ops.gptq_gemm
     (vllm/_custom_ops.py:558-577), ops.awq_gemm (:525-536) and triton_w4a16_gemm
     (mixed_precision/triton_w4a16.py:164-270).  With fuse_silu_mul, x is the
@@ -141,8 +141,10 @@ def w4a16_gemm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, s
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     M = x2.shape[0]
+    if out is not None and (out.shape != (M, w.N) or out.dtype != x.dtype or not out.is_contiguous()):
+        raise RuntimeError(f"out must be a contiguous [{M}, {w.N}] tensor of the activation dtype")
     if MM_MIN_TOKENS <= M <= MM_MAX_TOKENS and not fuse_silu_mul and _mm_supported(w):
-        return w4a16_mm(x2, w, bias).reshape(x.shape[:-1] + (w.N,))
+        return w4a16_mm(x2, w, bias, out=out).reshape(x.shape[:-1] + (w.N,))
     if M > DEQUANT_MATMUL_MIN_TOKENS and not torch.cuda.is_current_stream_capturing():
         # many tokens (prompt processing): dequantise once and run a dense GEMM, as the reference
         # does from 256 tokens on (auto_awq.py:947-955; exllama reconstruct path q_gemm.cu:1509-1522)
@@ -150,11 +152,12 @@ def w4a16_gemm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, s
             act = torch.empty((M, w.K), dtype=x.dtype, device=x.device)
             silu_and_mul(act, x2.contiguous())
             x2 = act
-        out = torch.matmul(x2, w4a16_dequantize(w))
+        res = torch.matmul(x2, w4a16_dequantize(w), out=out)
         if bias is not None:
-            out.add_(bias)
-        return out.reshape(x.shape[:-1] + (w.N,))
-    out = torch.empty((M, w.N), dtype=x.dtype, device=x.device)
+            res.add_(bias)
+        return res.reshape(x.shape[:-1] + (w.N,))
+    if out is None:
+        out = torch.empty((M, w.N), dtype=x.dtype, device=x.device)
     L = _lib.lib()
     ws_bytes = L.mi355q_w4a16_workspace_bytes(M, w.N, w.K, w.G)
     ws = _workspace(x.device, ws_bytes)
@@ -168,7 +171,8 @@ def _mm_supported(w: PackedW4) -> bool:
     return bool(_lib.lib().mi355q_w4a16_mm_supported(w.N, w.K, w.G, w.tile))
 
 
-def w4a16_mm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, silu_pairs: bool = False) -> torch.Tensor:
+def w4a16_mm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, silu_pairs: bool = False,
+             out: torch.Tensor | None = None) -> torch.Tensor:
     """[tokens, K] @ dequant(w) for prompt-sized token counts on the tiled matrix-core kernel: the packed
     weight is read once per 64 tokens and never expanded in memory.  Stands in for the many-token
     routes of ops.gptq_gemm (q_gemm.cu:1509-1522) and awq (auto_awq.py:947-955).  With silu_pairs
@@ -182,7 +186,8 @@ def w4a16_mm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, sil
         raise RuntimeError("w4a16_mm: silu_pairs needs a weight repacked with pair_halves=True")
     M = x.shape[0]
     L = _lib.lib()
-    out = torch.empty((M, w.N // 2 if silu_pairs else w.N), dtype=x.dtype, device=x.device)
+    if out is None:
+        out = torch.empty((M, w.N // 2 if silu_pairs else w.N), dtype=x.dtype, device=x.device)
     need = L.mi355q_w4a16_mm_workspace_bytes(M, w.N, w.K, w.G, w.tile)
     ws = _workspace(x.device, need + COUNTER_BYTES) if need else None
     check(L.mi355q_w4a16_mm(x.data_ptr(), x.stride(0), w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc), _ptr(bias),
@@ -286,22 +291,25 @@ def awq_dequantize(qweight: PackedW4, scales, zeros, split_k_iters: int, thx: in
 class PackedMoeW4:
     """Kernel-layout 4-bit weights of all experts of one projection (output of `moe_w4a16_repack`)."""
 
-    __slots__ = ("packed", "scales", "zc", "E", "K", "N", "G", "tile")
+    __slots__ = ("packed", "scales", "zc", "E", "K", "N", "G", "tile", "pair_halves")
 
-    def __init__(self, packed, scales, zc, E, K, N, G, tile):
+    def __init__(self, packed, scales, zc, E, K, N, G, tile, pair_halves=False):
         self.packed, self.scales, self.zc, self.E, self.K, self.N, self.G, self.tile = packed, scales, zc, E, K, N, G, tile
+        self.pair_halves = pair_halves
 
     def expert(self, e: int) -> PackedW4:
         return PackedW4(self.packed[e], self.scales[e], None if self.zc is None else self.zc[e], self.K, self.N,
-                        self.G, self.tile)
+                        self.G, self.tile, self.pair_halves)
 
 
 def moe_w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor | None,
-                     group_size: int) -> PackedMoeW4:
+                     group_size: int, pair_halves: bool = False) -> PackedMoeW4:
     """MoE WNA16 checkpoint-side layout (moe_wna16.py:204-330 after its loader conversions,
     :516-638) -> kernel layout.  qweight uint8 [E, N, K/2], two 4-bit values per byte along K with
     the even k in the low nibble; scales [E, N, K/G]; qzeros uint8 [E, N/2, K/G] (even n low) or
-    None for symmetric uint4b8."""
+    None for symmetric uint4b8.  pair_halves (the merged w13 projection): gate_i next to up_i, for
+    the SiluAndMul epilogue -- granted only where the layer shape supports it (see the result's
+    `pair_halves`)."""
     if qweight.dtype != torch.uint8 or qweight.dim() != 3:
         raise RuntimeError("moe qweight must be uint8 [E, N, K/2]")
     E, N, K2 = qweight.shape
@@ -312,6 +320,7 @@ def moe_w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.
     if qzeros is not None and (qzeros.dtype != torch.uint8 or qzeros.shape != (E, N // 2, K // G)):
         raise RuntimeError(f"moe qzeros must be uint8 [{E}, {N // 2}, {K // G}]")
     tile = _lib.lib().mi355q_w4a16_choose_strip(K, N, G)
+    pair_halves = bool(pair_halves) and w4a16_gate_up_silu_supported(K, N, G)
     packed = torch.empty((E, K * N // 8), dtype=torch.int32, device=qweight.device)
     sc = torch.empty((E, N // tile, K // G, tile), dtype=scales.dtype, device=qweight.device)
     zc = None if qzeros is None else torch.empty((E, N // tile, K // G, tile), dtype=scales.dtype, device=qweight.device)
@@ -323,12 +332,12 @@ def moe_w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.
             # [K/G, N/8], sequential nibbles (reshape gives canonical strides even when K/G == 1)
             qz = qzeros[e].t().contiguous().reshape(-1).view(K // G, N // 2).view(torch.int32)
         w = w4a16_repack(qw, scales[e].t().contiguous(), qz, G, _lib.W_GPTQ,
-                         _lib.ZP_CONST if qz is None else _lib.ZP_NSEQ, tile)
+                         _lib.ZP_CONST if qz is None else _lib.ZP_NSEQ, tile, pair_halves)
         packed[e].copy_(w.packed)
         sc[e].copy_(w.scales)
         if zc is not None:
             zc[e].copy_(w.zc.view(N // tile, K // G, tile))
-    return PackedMoeW4(packed, sc, zc, E, K, N, G, tile)
+    return PackedMoeW4(packed, sc, zc, E, K, N, G, tile, pair_halves)
 
 
 def topk_softmax(topk_weights: torch.Tensor, topk_ids: torch.Tensor, token_expert_indices: torch.Tensor | None,
@@ -346,20 +355,24 @@ def topk_softmax(topk_weights: torch.Tensor, topk_ids: torch.Tensor, token_exper
 
 
 def moe_w4a16_gemm(x: torch.Tensor, w: PackedMoeW4, expert_ids: torch.Tensor, x_row_div: int,
-                   fuse_silu_mul: bool = False) -> torch.Tensor:
+                   fuse_silu_mul: bool = False, silu_pairs: bool = False) -> torch.Tensor:
     """Row r of the result = x[r // x_row_div] (or silu-mul of x[r]) @ dequant(expert expert_ids[r]).
-    Stands in for ops.moe_wna16_gemm (vllm/_custom_ops.py:2307-2342) at decode sizes."""
+    Stands in for ops.moe_wna16_gemm (vllm/_custom_ops.py:2307-2342) at decode sizes.  silu_pairs
+    (experts repacked with pair_halves): SiluAndMul of the projection in the epilogue, [slots, N/2]."""
     _need_cuda(x, w.packed, expert_ids)
     if expert_ids.dtype != torch.int32 or not expert_ids.is_contiguous():
         raise RuntimeError("moe_w4a16_gemm: expert_ids must be a contiguous int32 tensor")
+    if silu_pairs and (fuse_silu_mul or not w.pair_halves):
+        raise RuntimeError("moe_w4a16_gemm: silu_pairs needs experts repacked with pair_halves and no prologue")
     slots = expert_ids.numel()
     Kx = w.K * (2 if fuse_silu_mul else 1)
     if x.dim() != 2 or x.shape[1] != Kx or x.stride(1) != 1 or x.shape[0] * x_row_div < slots:
         raise RuntimeError(f"moe_w4a16_gemm: input must be [>= {-(-slots // x_row_div)}, {Kx}]")
-    out = torch.empty((slots, w.N), dtype=x.dtype, device=x.device)
+    out = torch.empty((slots, w.N // 2 if silu_pairs else w.N), dtype=x.dtype, device=x.device)
+    mode = 2 if silu_pairs else int(fuse_silu_mul)
     check(_lib.lib().mi355q_moe_w4a16_gemm(x.data_ptr(), x.stride(0), x_row_div, w.packed.data_ptr(),
                                            w.scales.data_ptr(), _ptr(w.zc), expert_ids.data_ptr(), out.data_ptr(),
-                                           slots, w.E, w.N, w.K, w.G, w.tile, _dt(x), int(fuse_silu_mul), _stream()))
+                                           slots, w.E, w.N, w.K, w.G, w.tile, _dt(x), mode, _stream()))
     return out
 
 
@@ -422,8 +435,10 @@ def w8a16_gemm(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, bloc
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     M = x2.shape[0]
+    if out is not None and (out.shape != (M, w.N) or out.dtype != x.dtype or not out.is_contiguous()):
+        raise RuntimeError(f"out must be a contiguous [{M}, {w.N}] tensor of the activation dtype")
     if MM_MIN_TOKENS <= M <= MM_MAX_TOKENS and not fuse_silu_mul and _mm_supported(w):
-        return w4a16_mm(x2, w, bias).reshape(x.shape[:-1] + (w.N,))
+        return w4a16_mm(x2, w, bias, out=out).reshape(x.shape[:-1] + (w.N,))
     if M > DEQUANT_MATMUL_MIN_TOKENS and not torch.cuda.is_current_stream_capturing():
         out = torch.nn.functional.linear(x2, w8a16_dequantize(weight, scales, block, x.dtype), bias)
         return out.reshape(x.shape[:-1] + (N,))

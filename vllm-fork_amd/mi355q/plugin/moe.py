@@ -21,9 +21,17 @@ from .parallel import (get_tensor_model_parallel_rank, get_tensor_model_parallel
                        tensor_model_parallel_all_reduce)
 from .registry import QuantizationConfig, QuantizeMethodBase, register_quantization_config
 
-# slots (tokens x topk) up to which every slot streams its expert's weights on its own; above, tokens
-# are grouped per expert and run through dequantise + dense GEMM
-SLOT_ROUTE_MAX = 64
+# Three routes for the routed experts:
+#   slots (tokens x topk) <= local experts: every slot streams its own expert's weights (decode GEMV
+#     with the expert indirection); no token sort, capturable;
+#   more slots, up to ALL_EXPERTS_MAX_TOKENS tokens: every local expert runs over ALL tokens (its
+#     weights are read once, and at these sizes a projection costs what its weights cost to
+#     stream, so rows an expert was not selected for are free); the combine picks each token's
+#     selected rows.  No data-dependent shapes: capturable;
+#   prompt-sized batches outside graph capture: tokens grouped per expert on the host, dequantise +
+#     dense GEMM per expert (compute-bound there, so the unselected rows would not be free).
+ALL_EXPERTS_MAX_TOKENS = 64
+FORCE_ROUTE: str | None = None   # tests: "slots" | "all_experts" | "grouped"
 
 
 def convert_awq_tensor(tensor: torch.Tensor, tensor_type: str) -> torch.Tensor:
@@ -187,7 +195,8 @@ class MoeWNA16Method(QuantizeMethodBase):
     def process_weights_after_loading(self, layer) -> None:
         z13 = layer.w13_qzeros.data if self.quant_config.has_zp else None
         z2 = layer.w2_qzeros.data if self.quant_config.has_zp else None
-        layer.w13_packed = ops.moe_w4a16_repack(layer.w13_qweight.data, layer.w13_scales.data, z13, layer.group_size)
+        layer.w13_packed = ops.moe_w4a16_repack(layer.w13_qweight.data, layer.w13_scales.data, z13, layer.group_size,
+                                                pair_halves=True)
         layer.w2_packed = ops.moe_w4a16_repack(layer.w2_qweight.data, layer.w2_scales.data, z2, layer.group_size)
         for name in ("w13_qweight", "w2_qweight", "w13_scales", "w2_scales", "w13_qzeros", "w2_qzeros"):
             if name in layer._parameters:
@@ -215,7 +224,36 @@ def fused_experts(x: torch.Tensor, w13: ops.PackedMoeW4, w2: ops.PackedMoeW4, to
         ids = expert_map[ids.long()].to(torch.int32)
     ids = ids.contiguous()
     slots = T * topk
-    if slots <= SLOT_ROUTE_MAX or torch.cuda.is_current_stream_capturing():
+    capturing = torch.cuda.is_current_stream_capturing()
+    if FORCE_ROUTE is not None:
+        route = FORCE_ROUTE
+    elif slots <= w13.E:
+        route = "slots"
+    elif T <= ALL_EXPERTS_MAX_TOKENS or capturing:
+        route = "all_experts"
+    else:
+        route = "grouped"
+    if route == "all_experts":
+        E = w13.E
+        ys = torch.empty((E + 1, T, H), dtype=x.dtype, device=x.device)
+        ys[E].zero_()                                   # what a slot of an absent expert contributes
+        act = torch.empty((T, w2.K), dtype=x.dtype, device=x.device)
+        for e in range(E):
+            w13_e = w13.expert(e)
+            if not w13.pair_halves:
+                ops.silu_and_mul(act, ops.w4a16_gemm(x, w13_e))
+            elif T < ops.MM_MIN_TOKENS or not ops._mm_supported(w13_e):   # SiluAndMul in the projection's epilogue
+                act, _ = ops.w4a16_gate_up_silu(x, None, None, 0.0, w13_e, add_norm=False)
+            else:
+                act = ops.w4a16_mm(x, w13_e, silu_pairs=True)
+            ops.w4a16_gemm(act, w2.expert(e), out=ys[e])
+        sel = ids.view(T, topk).long()
+        sel = torch.where(sel < 0, torch.full_like(sel, E), sel)
+        y = ys[sel, torch.arange(T, device=x.device)[:, None]].contiguous()       # [T, topk, H]
+    elif route == "slots" and w13.pair_halves:
+        act = ops.moe_w4a16_gemm(x, w13, ids, topk, silu_pairs=True)   # SiluAndMul in the epilogue
+        y = ops.moe_w4a16_gemm(act, w2, ids, 1)
+    elif route == "slots":
         h = ops.moe_w4a16_gemm(x, w13, ids, topk)
         if w2.G % 128 == 0:      # SiluAndMul runs in the prologue of the second GEMM
             y = ops.moe_w4a16_gemm(h, w2, ids, 1, fuse_silu_mul=True)
@@ -230,6 +268,8 @@ def fused_experts(x: torch.Tensor, w13: ops.PackedMoeW4, w2: ops.PackedMoeW4, to
                 continue
             rows = (ids == e).nonzero().view(-1)
             h = torch.matmul(x.index_select(0, rows // topk), ops.w4a16_dequantize(w13.expert(e)))
+            if w13.pair_halves:
+                h = ops.unpair_halves(h)
             act = torch.empty((h.shape[0], h.shape[1] // 2), dtype=x.dtype, device=x.device)
             ops.silu_and_mul(act, h)
             y.index_copy_(0, rows, torch.matmul(act, ops.w4a16_dequantize(w2.expert(e))))
