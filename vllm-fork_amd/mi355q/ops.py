@@ -435,10 +435,6 @@ def w8a16_gemm(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, bloc
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     M = x2.shape[0]
-    if out is not None and (out.shape != (M, w.N) or out.dtype != x.dtype or not out.is_contiguous()):
-        raise RuntimeError(f"out must be a contiguous [{M}, {w.N}] tensor of the activation dtype")
-    if MM_MIN_TOKENS <= M <= MM_MAX_TOKENS and not fuse_silu_mul and _mm_supported(w):
-        return w4a16_mm(x2, w, bias, out=out).reshape(x.shape[:-1] + (w.N,))
     if M > DEQUANT_MATMUL_MIN_TOKENS and not torch.cuda.is_current_stream_capturing():
         out = torch.nn.functional.linear(x2, w8a16_dequantize(weight, scales, block, x.dtype), bias)
         return out.reshape(x.shape[:-1] + (N,))
