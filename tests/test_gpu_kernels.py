@@ -196,6 +196,45 @@ def test_w4a16_mm_silu_pairs_and_routing(monkeypatch):
     assert (to_bits(plain) == y).mean() > 0.98
 
 
+@pytest.mark.parametrize("M,K,N,G,awq", [(1, 4096, 4096, 64, False), (3, 4096, 28672, 32, False), (1, 14336, 4096, 32, True),
+                                          (2, 4096, 6144, 64, True), (16, 1024, 4096, 32, False)])
+def test_w4a16_small_scale_groups_on_the_decode_kernel(M, K, N, G, awq):
+    """Scale groups of 32 / 64 input channels (AutoRound and GPTQ checkpoints use them) on layers wide
+    enough for the one-workgroup-per-strip kernel: group sums folded inside the 128-k chunk.  Same
+    bar as group size 128; the add+RMSNorm prologue and the SiLU-pair epilogue work on them too."""
+    rng = np.random.default_rng(K + N + G)
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    a = orc.f32_to_h16(0.25 * rng.standard_normal((M, K)).astype(np.float32))
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N))).astype(np.float32))
+    if awq:
+        z = rng.integers(0, 16, size=(K // G, N), dtype=np.int32)
+        qw, qz = orc.pack_cols(q, awq_order=True), orc.pack_cols(z, awq_order=True)
+        kw = dict(layout=orc.W_AWQ, zp_mode=orc.ZP_AWQ)
+        rp = lambda **k: ops.w4a16_repack(i32(qw), to_dev(s), i32(qz), G, _lib.W_AWQ, _lib.ZP_AWQ, **k)
+    else:
+        qw, qz, kw = orc.gptq_pack(q), None, {}
+        rp = lambda **k: ops.w4a16_repack(i32(qw), to_dev(s), None, G, **k)
+    w = rp()
+    assert N // w.tile >= 128     # wide enough: not the split-K capable fallback
+    ref = orc.w4a16_gemm(a, qw, s, qz, None, G=G, **kw)
+    out = ops.w4a16_gemm(to_dev(a), w)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=1e-2)
+    assert (to_bits(out) == ref).mean() > 0.98
+    assert np.array_equal(to_bits(ops.w4a16_dequantize(w)), orc.f32_to_h16(orc.w4a16_dequant(qw, s, qz, G=G, **kw)))
+    if M <= 4:
+        r = orc.f32_to_h16(rng.standard_normal((M, K)).astype(np.float32))
+        nw = orc.f32_to_h16((1 + 0.1 * rng.standard_normal(K)).astype(np.float32))
+        xn, rn = orc.fused_add_rms_norm(a, r, nw, 1e-5)
+        y, res = ops.w4a16_gemm_add_rms_norm(to_dev(a), to_dev(r), to_dev(nw), 1e-5, w)
+        assert np.array_equal(to_bits(res), rn)
+        refn = orc.w4a16_gemm(xn, qw, s, qz, None, G=G, **kw)
+        assert (to_bits(y) == refn).mean() > 0.98
+        if ops.w4a16_gate_up_silu_supported(K, N, G):
+            wp = rp(pair_halves=True)
+            act, _ = ops.w4a16_gate_up_silu(to_dev(xn), None, None, 1e-5, wp, add_norm=False)
+            assert (to_bits(act) == orc.silu_and_mul(refn)).mean() > 0.97
+
+
 def test_w4a16_many_token_route_vs_oracle(monkeypatch):
     """Above the token threshold the weight is dequantised to 16-bit and fed to a dense GEMM
     (exllama reconstruct route, csrc/quantization/gptq/q_gemm.cu:1509-1522): compare with the

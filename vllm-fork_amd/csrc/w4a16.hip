@@ -167,13 +167,20 @@ static int check_shape(int K, int N, int& G) {
   return 0;
 }
 
-// a tile must not straddle a scale group: 32 * KT input channels per tile
+// Strip widths the split-K capable kernel (w4a16_skinny_kernel) can run: one of its three widths,
+// and a 1 KiB tile (32 * KT input channels) must not straddle a scale group.
+static bool legacy_kernel_ok(int sw, int K, int G) {
+  if (sw != 64 && sw != 32 && sw != 16) return false;
+  const int kt = 4 / (sw >> 4);
+  return chunk_steps(G) % kt == 0 && K % (32 * kt) == 0;
+}
+// Is `sw` a usable strip width for a [K, N] layer with group size G?  Whole 128-k chunks with
+// groups of 32, 64 or a multiple of 128 channels suit every width (the decode kernel folds a group
+// inside a chunk); other shapes need what the split-K capable kernel needs.
 static bool tile_ok(int sw, int K, int G) {
   if (sw < 16 || sw > 128 || sw % 16) return false;
-  const int ns = sw >> 4;
-  if (chunk_rule(ns)) return K % 128 == 0 && G % 128 == 0;
-  const int kt = 4 / ns;
-  return chunk_steps(G) % kt == 0 && K % (32 * kt) == 0;
+  if (K % 128 == 0 && (G % 128 == 0 || G == 64 || G == 32)) return true;
+  return legacy_kernel_ok(sw, K, G);
 }
 // strip widths the split-K capable kernel (w4a16_skinny_kernel) is built for
 static bool legacy_tile(int sw) { return sw == 64 || sw == 32 || sw == 16; }
@@ -208,7 +215,7 @@ extern "C" int mi355q_w4a16_choose_tile(int K, int N, int G) {
   const char* env = getenv("MI355Q_TILE");
   if (env && tile_ok(atoi(env), K, G)) return atoi(env);
   int sw = N >= 16384 ? 64 : (N >= 6144 ? 32 : 16);
-  while (sw < 64 && !tile_ok(sw, K, G)) sw <<= 1;
+  while (sw < 64 && !legacy_kernel_ok(sw, K, G)) sw <<= 1;   // the widths the split-K capable kernel runs
   return sw;
 }
 
@@ -697,7 +704,8 @@ struct BurstParams {
   float eps;
   int M, N, K;
   int chunks;   // K / 128
-  int gchunks;  // chunks per scale group (G / 128)
+  int groups;   // K / G
+  int kpg;      // 32-k steps per scale group (G / 32)
   int rows_pp;  // activation rows per pass
   int nw;       // waves per workgroup; chunks == nw * CPW * bursts
   int bursts;
@@ -715,7 +723,9 @@ static unsigned long long* g_burst_stamps = nullptr;
 
 constexpr int BURST_XV = 2;  // 16-byte activation vectors a thread may hold in the single-row prologue
 
-template <typename DT, int NS, int CPW, bool HAS_ZC, int PRO>
+// SMALLG: scale groups of 32 or 64 input channels (one or two k-steps): the group sum is folded into
+// the total inside the k-step loop instead of once per 128-k chunk.
+template <typename DT, int NS, int CPW, bool HAS_ZC, int PRO, bool SMALLG = false>
 __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel(const BurstParams p) {
   constexpr int SW = 16 * NS, QW = 4 * NS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -725,7 +735,7 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
   const int kq = lane >> 4, ml = lane & 15;
   const int row0 = blockIdx.z * p.rows_pp;
   const int Mt = min(p.rows_pp, p.M - row0);
-  const int groups = p.chunks / p.gchunks;
+  const int groups = p.groups;
   const int astride = p.K + 8;  // +16 B per row: rows land on different LDS banks
 
   float* red = reinterpret_cast<float*>(smem);                                 // [nw][rows_pp][SW]
@@ -974,6 +984,28 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
       f32x4 acc[NS], acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < NS; s++) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // fold one scale group's sums into the totals: this lane's outputs are channels
+      // QW kq + 4 sub + r of the strip
+      auto flush = [&](int g) {
+        const uint16_t* sg = sc_l + (size_t)g * SW + QW * kq;
+        const uint16_t* zg = zc_l + (size_t)g * SW + QW * kq;
+#pragma unroll
+        for (int sub = 0; sub < NS; sub++) {
+          const u32x2 sv = *reinterpret_cast<const u32x2*>(sg + 4 * sub);
+          u32x2 zv = u32x2{0u, 0u};
+          if constexpr (HAS_ZC) zv = *reinterpret_cast<const u32x2*>(zg + 4 * sub);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const uint32_t sw_ = sv[r >> 1];
+            const float s = (r & 1) ? hi(sw_) : lo(sw_);
+            float z;
+            if constexpr (HAS_ZC) z = (r & 1) ? hi(zv[r >> 1]) : lo(zv[r >> 1]);
+            else z = DT::int4_bias + 8.0f;
+            const float d = __builtin_fmaf(-z, acc1[r], acc[sub][r]);
+            tot[sub][r] = __builtin_fmaf(s, d, tot[sub][r]);
+          }
+        }
+      };
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
         const u32x4 bf = *reinterpret_cast<const u32x4*>(arow + (c * 4 + ks) * 32);
@@ -984,27 +1016,17 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
           acc[sub] = mfma16<DT>(dequant_frag<DT>(w[i][e >> 2][e & 3]), bf, acc[sub]);
         }
         __builtin_amdgcn_sched_barrier(0);  // dequantised fragments of one k-step live at a time
-      }
-      // this lane's outputs: channels QW kq + 4 sub + r of the strip
-      const int g = c / p.gchunks;
-      const uint16_t* sg = sc_l + (size_t)g * SW + QW * kq;
-      const uint16_t* zg = zc_l + (size_t)g * SW + QW * kq;
+        if constexpr (SMALLG) {
+          if (((ks + 1) % p.kpg) == 0) {   // kpg is 1 or 2 here: a group ends inside the chunk
+            flush((c * 4 + ks) / p.kpg);
+            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int sub = 0; sub < NS; sub++) {
-        const u32x2 sv = *reinterpret_cast<const u32x2*>(sg + 4 * sub);
-        u32x2 zv = u32x2{0u, 0u};
-        if constexpr (HAS_ZC) zv = *reinterpret_cast<const u32x2*>(zg + 4 * sub);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const uint32_t sw_ = sv[r >> 1];
-          const float s = (r & 1) ? hi(sw_) : lo(sw_);
-          float z;
-          if constexpr (HAS_ZC) z = (r & 1) ? hi(zv[r >> 1]) : lo(zv[r >> 1]);
-          else z = DT::int4_bias + 8.0f;
-          const float d = __builtin_fmaf(-z, acc1[r], acc[sub][r]);
-          tot[sub][r] = __builtin_fmaf(s, d, tot[sub][r]);
+            for (int s = 0; s < NS; s++) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
+      if constexpr (!SMALLG) flush((c * 4 + 3) / p.kpg);
       // the slot just consumed is refilled at once: CPW chunks stay in flight per wave to the end
       if (burst + 1 < p.bursts) issue_chunk(burst + 1, i);
       // keep the chunks' MFMA chains apart: interleaving them would hold several accumulator sets live
@@ -1072,7 +1094,7 @@ struct BurstPlan {
 // with a per-wave share the kernel is built for; rows per pass from what is left of the LDS.
 static BurstPlan plan_burst(int M, int K, int G, int ns, bool has_zc) {
   BurstPlan bp{false, 0, 0, 0, 0, 0};
-  if (G % 128 || K % 128) return bp;
+  if ((G % 128 && G != 64 && G != 32) || K % 128) return bp;
   const int chunks = K / 128, groups = K / G;
   for (int nw = 16; nw >= 2 && !bp.ok; nw--) {
     if (chunks % nw) continue;
@@ -1098,6 +1120,17 @@ static BurstPlan plan_burst(int M, int K, int G, int ns, bool has_zc) {
 template <typename DT, int NS, int CPW, int PRO>
 static int launch_burst2(const BurstParams& p, size_t lds, hipStream_t stream) {
   dim3 grid(p.N / (16 * NS), 1, (p.M + p.rows_pp - 1) / p.rows_pp), block(p.nw * 64);
+  if (p.kpg < 4) {   // 32- or 64-wide scale groups (built without the SiLU prologue)
+    if constexpr (PRO != PRO_SILU) {
+      if (p.zc)
+        hipLaunchKernelGGL((w4a16_burst_kernel<DT, NS, CPW, true, PRO, true>), grid, block, lds, stream, p);
+      else
+        hipLaunchKernelGGL((w4a16_burst_kernel<DT, NS, CPW, false, PRO, true>), grid, block, lds, stream, p);
+      return check_launch("w4a16_burst_kernel");
+    } else {
+      return set_error(MI355Q_EINVAL, "w4a16_gemm: the SiLU prologue needs a group size that is a multiple of 128");
+    }
+  }
   if (p.zc)
     hipLaunchKernelGGL((w4a16_burst_kernel<DT, NS, CPW, true, PRO>), grid, block, lds, stream, p);
   else
@@ -1750,7 +1783,8 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
       bp.ok = bp.ok && pro != PRO_ADDNORM && bias == nullptr && moe->expert_ids && moe->x_row_div >= 1;
       bp.rows_pp = 1;
     }
-    if (bp.ok && !(nb && atoi(nb)) && (!legacy_tile(sw) || !want_split)) {
+    if (G % 128 && pro == PRO_SILU) bp.ok = false;   // that prologue is built for 128-multiples only
+    if (bp.ok && !(nb && atoi(nb)) && (!legacy_kernel_ok(sw, K, G) || !want_split)) {
       BurstParams b;
       b.expert_ids = nullptr; b.x_row_div = 1; b.wp_estride = 0; b.sc_estride = 0;
       if (moe) {
@@ -1770,7 +1804,7 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
         b.res_in = (const uint16_t*)na->res_in; b.res_out = (uint16_t*)na->res_out;
         b.norm_w = (const uint16_t*)na->norm_w; b.eps = na->eps;
       }
-      b.M = M; b.N = N; b.K = K; b.chunks = K / 128; b.gchunks = G / 128;
+      b.M = M; b.N = N; b.K = K; b.chunks = K / 128; b.groups = K / G; b.kpg = G / 32;
       b.rows_pp = bp.rows_pp; b.nw = bp.nw; b.bursts = bp.bursts;
       b.stamps = g_burst_stamps;
       b.epi_silu = epi_silu;
@@ -1788,7 +1822,7 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
   }
   MI355Q_REQUIRE(!epi_silu, "w4a16_gemm: the SiLU-pair epilogue needs a layer the burst kernel serves "
                             "(group size a multiple of 128, at least 128 strips)");
-  MI355Q_REQUIRE(legacy_tile(sw), "w4a16_gemm: strip width %d needs a group size that is a multiple of 128 and K = 128 * waves * {2,4,7}", sw);
+  MI355Q_REQUIRE(legacy_kernel_ok(sw, K, G), "w4a16_gemm: strip width %d with group size %d needs K = 128 * waves * {2,4,7} and at least 128 strips", sw, G);
   const int CS = chunk_steps(G);
   SkinnyParams p;
   p.x = (const uint16_t*)x;
@@ -1973,7 +2007,7 @@ extern "C" int mi355q_moe_w4a16_gemm(const void* x, int ldx, int x_row_div, cons
 extern "C" int mi355q_w4a16_choose_strip(int K, int N, int G) {
   if (G <= 0) G = K;
   const int legacy = mi355q_w4a16_choose_tile(K, N, G);
-  if (getenv("MI355Q_TILE") || G % 128 || K % 128) return legacy;
+  if (getenv("MI355Q_TILE") || (G % 128 && G != 64 && G != 32) || K % 128) return legacy;
   int best = 0;
   double best_cost = 1e30;
   const int cands[4] = {1, 2, 4, 7};
