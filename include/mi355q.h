@@ -276,6 +276,20 @@ int mi355q_w8a16_gemm(const void* a, int lda, const void* w, const float* scales
 int mi355q_w8a16_dequantize(const void* w, const float* scales, void* out, int N, int K,
                             int block_n, int block_k, int act_dtype, mi355q_stream_t stream);
 
+/*
+ * 8-bit integer weight-only linear (GPTQ 8 bits, symmetric: scalar type uint8b128):
+ * C[M,N] = A[M,K] * ((q - 128) * scale)^T (+ bias), same kernels and rounding as mi355q_w8a16_gemm.
+ *   w      : uint8 [N, K], the checkpoint's values re-ordered from int32 [K/4, N] (four consecutive
+ *            k per word, least significant byte first: auto_gptq.py:381-445 with pack_factor 4)
+ *   scales : fp32 [N, K / group_k] (group_k = K: one scale per output channel), group_k a multiple of 16
+ * Replaces ops.gptq_gemm with bit = 8 (vllm/_custom_ops.py:558-577; q_gemm.cu:1384-1419 with
+ * qdq_8.cuh) and its reconstruct route (mi355q_wi8a16_dequantize + dense GEMM for many tokens).
+ */
+int mi355q_wi8a16_gemm(const void* a, int lda, const void* w, const float* scales, const void* bias,
+                       void* c, int M, int N, int K, int group_k, int act_dtype, mi355q_stream_t stream);
+int mi355q_wi8a16_dequantize(const void* w, const float* scales, void* out, int N, int K, int group_k,
+                             int act_dtype, mi355q_stream_t stream);
+
 /* ------------------------------------------------------------------ */
 /* Unquantized skinny linear (lm_head, bf16 decode comparator)         */
 /* ------------------------------------------------------------------ */

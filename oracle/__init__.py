@@ -297,3 +297,33 @@ def apply_repetition_penalties(logits, prompt_mask, output_mask, penalties):
     pen = np.ascontiguousarray(penalties, dtype=np.float32)
     lib().orc_apply_repetition_penalties(_p(lg), _p(pm), _p(om), _p(pen), _i(B), _i(V))
     return lg
+
+
+# ---- GPTQ 8 bits (symmetric) ---------------------------------------------------
+def gptq8_pack(q):
+    """[K, N] values 0..255 -> int32 [K/4, N], four consecutive k per word, least significant byte
+    first (pack_rows with 8 bits: vllm/model_executor/layers/quantization/utils/quant_utils.py:828-849)."""
+    q = np.ascontiguousarray(q, dtype=np.uint32)
+    K, N = q.shape
+    r = q.reshape(K // 4, 4, N)
+    return (r[:, 0] | (r[:, 1] << 8) | (r[:, 2] << 16) | (r[:, 3] << 24)).astype(np.uint32).view(np.int32)
+
+
+def gptq8_dequant(q, scales_bits, G, dt=BF16, round_weight=False):
+    """W[k, n] = (q[k, n] - 128) * s[k // G, n] in fp32 (uint8b128: csrc/quantization/gptq/qdq_8.cuh
+    of the reference, zero point 128 for symmetric checkpoints); optionally rounded to the activation
+    dtype as the reconstruct route does (q_gemm.cu:1509-1522)."""
+    s = h16_to_f32(scales_bits, dt)
+    W = (np.asarray(q, dtype=np.float32) - np.float32(128)) * np.repeat(s, G, axis=0)
+    return h16_to_f32(f32_to_h16(W, dt), dt) if round_weight else W
+
+
+def gptq8_gemm(a_bits, q, scales_bits, G, bias_bits=None, dt=BF16, round_weight=False):
+    """round(a @ W) (+ bias added to the rounded product, as output.add_(bias) does), fp32 products
+    summed in float64 (order-free stand-in for the kernels' fp32 accumulation)."""
+    W = gptq8_dequant(q, scales_bits, G, dt, round_weight).astype(np.float64)
+    y = h16_to_f32(a_bits, dt).astype(np.float64) @ W
+    out = f32_to_h16(y.astype(np.float32), dt)
+    if bias_bits is not None:
+        out = f32_to_h16(h16_to_f32(out, dt) + h16_to_f32(bias_bits, dt)[None, :], dt)
+    return out

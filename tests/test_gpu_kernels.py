@@ -824,6 +824,33 @@ def test_w8a16_many_token_route(monkeypatch):
     np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("M,N,K,G,dt", [(1, 4096, 4096, 128, orc.BF16), (3, 1000, 512, 64, orc.BF16), (4, 256, 2048, -1, orc.FP16),
+                                        (16, 512, 1024, 32, orc.BF16)])
+def test_gptq_8bit_vs_oracle(M, N, K, G, dt, monkeypatch):
+    """8-bit symmetric GPTQ: W = (q - 128) * s (uint8b128).  Kernel against the oracle's restatement;
+    the many-token route (dequantise + dense GEMM) against the rounded-weight mode."""
+    rng = np.random.default_rng(M + N + K)
+    Ge = K if G == -1 else G
+    q = rng.integers(0, 256, size=(K, N), dtype=np.int32)
+    a = orc.f32_to_h16(0.25 * rng.standard_normal((M, K)).astype(np.float32), dt)
+    s = orc.f32_to_h16((0.004 * rng.random((K // Ge, N)) + 0.001).astype(np.float32), dt)
+    bias = orc.f32_to_h16(rng.standard_normal(N).astype(np.float32), dt)
+    w, sc = ops.gptq8_repack(i32(orc.gptq8_pack(q)), to_dev(s, dt), G)
+    assert w.shape == (N, K) and np.array_equal(w.cpu().numpy(), q.T.astype(np.uint8))
+    assert np.array_equal(sc.cpu().numpy(), f32(s, dt).T)
+    ref = orc.gptq8_gemm(a, q, s, Ge, None, dt)
+    out = ops.wi8a16_gemm(to_dev(a, dt), w, sc, G)
+    np.testing.assert_allclose(f32(to_bits(out), dt), f32(ref, dt), rtol=1e-2, atol=1e-2)
+    assert (to_bits(out) == ref).mean() > (0.97 if dt == orc.BF16 else 0.9)
+    deq = ops.wi8a16_dequantize(w, sc, G, TDT[dt])
+    assert np.array_equal(to_bits(deq), orc.f32_to_h16(orc.gptq8_dequant(q, s, Ge, dt).T, dt))
+    monkeypatch.setattr(ops, "DEQUANT_MATMUL_MIN_TOKENS", 0)
+    many = ops.wi8a16_gemm(to_dev(a, dt), w, sc, G, bias=to_dev(bias, dt))
+    ref_rw = orc.gptq8_gemm(a, q, s, Ge, None, dt, round_weight=True)
+    want = f32(ref_rw, dt) + f32(bias, dt)[None, :]
+    np.testing.assert_allclose(f32(to_bits(many), dt), want, rtol=2e-2, atol=2e-2)
+
+
 def test_w8a16_bad_arguments():
     w = torch.zeros((64, 128), dtype=torch.uint8, device=DEV)
     x = torch.zeros((1, 128), dtype=torch.bfloat16, device=DEV)

@@ -153,6 +153,30 @@ def test_gptq_act_order_checkpoint():
     assert (to_bits(lin2(to_dev(x))) == ref2).mean() > 0.98
 
 
+def test_gptq_8bit_checkpoint():
+    """bits=8 GPTQ config -> uint8b128 -> the 8-bit kernel class; bias added to the rounded product."""
+    rng = np.random.default_rng(15)
+    hidden, out_f, G, T = 1024, 768, 128, 3
+    cfg = AutoGPTQConfig.from_config({"bits": 8, "group_size": G, "desc_act": False, "sym": True})
+    with torch.device(DEV):
+        lin = RowParallelLinear(hidden, out_f, bias=True, params_dtype=torch.bfloat16, quant_config=cfg,
+                                prefix="mlp.down_proj", return_bias=False)
+    assert type(lin.quant_method.kernel).__name__ == "MI355XW8A16LinearKernel"
+    assert lin.qweight.shape == (hidden // 4, out_f)
+    q = rng.integers(0, 256, size=(hidden, out_f), dtype=np.int32)
+    s = orc.f32_to_h16((0.004 * rng.random((hidden // G, out_f)) + 0.001).astype(np.float32))
+    bias = orc.f32_to_h16(rng.standard_normal(out_f).astype(np.float32))
+    lin.weight_loader(lin.qweight, torch.from_numpy(orc.gptq8_pack(q)))
+    lin.weight_loader(lin.scales, to_dev(s).cpu())
+    lin.weight_loader(lin.bias, to_dev(bias).cpu())
+    lin.process_weights_after_loading()
+    x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    ref = orc.gptq8_gemm(x, q, s, G, bias)
+    got = lin(to_dev(x))
+    np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=1e-2)
+    assert (to_bits(got) == ref).mean() > 0.97
+
+
 def test_awq_linear_method_matches_oracle():
     rng = np.random.default_rng(1)
     K, N, G, T = 512, 768, 128, 3

@@ -134,9 +134,11 @@ def test_layers_route_to_the_gptq_and_awq_methods():
     assert isinstance(inner, AutoAWQLinearMethod)
     assert (inner.quant_config.group_size, inner.quant_config.zero_point) == (64, True)
 
-    with pytest.raises(NotImplementedError, match="Only 4-bit symmetric"):
-        make_config(weight_bits=8).get_quant_method(lin, "model.layers.0.mlp.down_proj")
-    with pytest.raises(NotImplementedError, match="Only 4-bit symmetric"):
+    inner8 = make_config(weight_bits=8).get_quant_method(lin, "model.layers.0.mlp.down_proj").scheme.inner_method
+    assert isinstance(inner8, AutoGPTQLinearMethod) and inner8.quant_config.weight_bits == 8
+    with pytest.raises(NotImplementedError, match="Only 4-bit and 8-bit symmetric"):
+        make_config(weight_bits=2).get_quant_method(lin, "model.layers.0.mlp.down_proj")
+    with pytest.raises(NotImplementedError, match="Only 4-bit and 8-bit symmetric"):
         make_config(sym=False).get_quant_method(lin, "model.layers.0.mlp.down_proj")
 
     moe = c.get_quant_method(DummyFusedMoE(), "model.layers.0.mlp.experts")

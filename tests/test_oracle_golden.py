@@ -49,6 +49,27 @@ def test_dequant_matches_quantize_weights_ref(golden, tag, G, zp):
     np.testing.assert_allclose(ref_from_q, w_ref, rtol=0, atol=0)
 
 
+def test_gptq8_dequant_matches_quantize_weights_ref(golden):
+    """8-bit symmetric (uint8b128): the oracle's (q - 128) * s reproduces w_ref of
+    quant_utils.quantize_weights, and its packer is the inverse of the byte order the kernel
+    operand uses (four consecutive k per int32, least significant byte first)."""
+    g = golden("quantize")
+    w_q, w_s, w_ref = g["u8b128_g128_w_q"], g["u8b128_g128_w_s"], g["u8b128_g128_w_ref"]
+    assert w_q.min() >= 0 and w_q.max() <= 255
+    ref_from_q = (w_q - 128).astype(np.float32) * np.repeat(w_s, 128, axis=0)
+    np.testing.assert_allclose(ref_from_q, w_ref, rtol=0, atol=0)
+    s_bits = orc.f32_to_h16(w_s)
+    W = orc.gptq8_dequant(w_q, s_bits, 128)
+    assert np.array_equal(W, (w_q - 128).astype(np.float32) * np.repeat(f32(s_bits), 128, axis=0))
+    packed = orc.gptq8_pack(w_q)
+    assert packed.shape == (w_q.shape[0] // 4, w_q.shape[1])
+    b = packed.view(np.uint8).reshape(packed.shape[0], packed.shape[1], 4)
+    assert np.array_equal(b.transpose(0, 2, 1).reshape(w_q.shape), w_q.astype(np.uint8))
+    a = orc.f32_to_h16(np.random.default_rng(0).standard_normal((2, w_q.shape[0])).astype(np.float32))
+    y = orc.gptq8_gemm(a, w_q, s_bits, 128)
+    np.testing.assert_allclose(f32(y), f32(a) @ W, rtol=1e-2, atol=1e-2)
+
+
 def test_w4a16_triton_cases(golden):
     """Inputs and expected outputs of test_triton_w4a16.py:112-162, tolerance of :162."""
     g = golden("w4a16_triton_cases")

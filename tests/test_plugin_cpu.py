@@ -147,11 +147,17 @@ def _kcfg(**kw):
 def test_kernel_selection_and_reasons(monkeypatch):
     assert choose_mp_linear_kernel(_kcfg()) is MI355XW4A16LinearKernel
     assert choose_mp_linear_kernel(_kcfg(weight_type=scalar_types.uint4, zero_points=True)) is MI355XW4A16LinearKernel
+    # 8-bit symmetric GPTQ weights have a kernel of their own (no reordering, no zero points)
+    from mi355q.plugin.mp_kernel import MI355XW8A16LinearKernel
+    assert choose_mp_linear_kernel(_kcfg(weight_type=scalar_types.uint8b128)) is MI355XW8A16LinearKernel
+    ok, reason = MI355XW4A16LinearKernel.can_implement(_kcfg(weight_type=scalar_types.uint8b128))
+    assert not ok and "not supported" in reason
+    with pytest.raises(ValueError, match="Failed to find a kernel"):
+        choose_mp_linear_kernel(_kcfg(weight_type=scalar_types.uint8b128, has_g_idx=True))
     # activation reordering is served when the whole of K is on the rank, refused when K is sharded
     assert choose_mp_linear_kernel(_kcfg(has_g_idx=True)) is MI355XW4A16LinearKernel
     for bad, why in ((dict(has_g_idx=True, partition_weight_shape=(2048, 6144)), "g_idx"),
                      (dict(act_type=torch.float32), "float16/bfloat16"),
-                     (dict(weight_type=scalar_types.uint8b128), "not supported"),
                      (dict(partition_weight_shape=(4096, 100)), "multiple of 64"),
                      (dict(group_size=100), "not divisible"), (dict(weight_type=scalar_types.uint4), "zero points")):
         ok, reason = MI355XW4A16LinearKernel.can_implement(_kcfg(**bad))

@@ -6,6 +6,10 @@
 // one per output channel, or one per (block_n x block_k) tile of W for block-quantised
 // checkpoints (then every lane's 16-element partial product is scaled before it is added).
 // The bias joins in fp32 before the single rounding, as in F.linear's GEMM epilogue.
+//
+// The same kernels serve 8-bit integer weights stored as bytes biased by 128 (GPTQ's uint8b128:
+// w = (q - 128) * scale): WT = 1 converts with v_cvt_f32_ubyte and takes the bias out through the
+// sum of the lane's activations, so the inner loop stays one convert + one fma per weight.
 #include "common.h"
 
 namespace mi355q {
@@ -27,13 +31,35 @@ __device__ inline f32x2 unpack2<FP16>(uint32_t u) {
   return r;
 }
 
-// dot product of 16 fp8 weights (one u32x4) with 16 16-bit activations (two u32x4)
+// weights of one dword as two pairs of floats: fp8 values (WT = 0) or raw bytes 0..255 (WT = 1)
+template <int WT>
+__device__ inline void w4_to_f32(uint32_t w, f32x2& lo, f32x2& hi) {
+  if constexpr (WT == 0) {
+    lo = fp8x2_to_f32(w, false);
+    hi = fp8x2_to_f32(w, true);
+  } else {
+    lo.x = (float)(w & 0xffu); lo.y = (float)((w >> 8) & 0xffu);
+    hi.x = (float)((w >> 16) & 0xffu); hi.y = (float)(w >> 24);
+  }
+}
+
+// sum of 16 16-bit activations (two u32x4)
 template <typename DT>
+__device__ inline float sum16(u32x4 x0, u32x4 x1) {
+  f32x2 acc = {0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; e++) acc += unpack2<DT>(x0[e]) + unpack2<DT>(x1[e]);
+  return acc.x + acc.y;
+}
+
+// dot product of 16 8-bit weights (one u32x4) with 16 16-bit activations (two u32x4)
+template <typename DT, int WT>
 __device__ inline float dot16(u32x4 w, u32x4 x0, u32x4 x1) {
   f32x2 acc = {0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 4; e++) {
-    const f32x2 wl = fp8x2_to_f32(w[e], false), wh = fp8x2_to_f32(w[e], true);
+    f32x2 wl, wh;
+    w4_to_f32<WT>(w[e], wl, wh);
     const uint32_t xa = e < 2 ? x0[2 * e] : x1[2 * e - 4];
     const uint32_t xb = e < 2 ? x0[2 * e + 1] : x1[2 * e - 3];
     acc += wl * unpack2<DT>(xa);
@@ -42,7 +68,7 @@ __device__ inline float dot16(u32x4 w, u32x4 x0, u32x4 x1) {
   return acc.x + acc.y;
 }
 
-template <typename DT, int MB, bool BLOCK_SCALE>
+template <typename DT, int MB, bool BLOCK_SCALE, int WT>
 __global__ __launch_bounds__(256) void w8a16_skinny_kernel(
     const uint16_t* __restrict__ a, int lda, const uint8_t* __restrict__ w,
     const float* __restrict__ scales, const uint16_t* __restrict__ bias, uint16_t* __restrict__ c,
@@ -90,12 +116,13 @@ __global__ __launch_bounds__(256) void w8a16_skinny_kernel(
 #pragma unroll
       for (int m = 0; m < MB; m++) {
         const u32x4 x0 = xs[m * kv8 + 2 * v], x1 = xs[m * kv8 + 2 * v + 1];
+        const float off = WT == 1 ? 128.0f * sum16<DT>(x0, x1) : 0.f;   // sum a (q - 128) = sum a q - 128 sum a
         if (BLOCK_SCALE) {
-          acc[0][m] += sa * dot16<DT>(wa, x0, x1);
-          acc[1][m] += sb * dot16<DT>(wb, x0, x1);
+          acc[0][m] += sa * (dot16<DT, WT>(wa, x0, x1) - off);
+          acc[1][m] += sb * (dot16<DT, WT>(wb, x0, x1) - off);
         } else {
-          acc[0][m] += dot16<DT>(wa, x0, x1);
-          acc[1][m] += dot16<DT>(wb, x0, x1);
+          acc[0][m] += dot16<DT, WT>(wa, x0, x1) - off;
+          acc[1][m] += dot16<DT, WT>(wb, x0, x1) - off;
         }
       }
     }
@@ -118,7 +145,7 @@ __global__ __launch_bounds__(256) void w8a16_skinny_kernel(
 }
 
 // W16[N,K] = round(fp8(W) * scale): the weight the dense-GEMM route multiplies with.
-template <typename DT>
+template <typename DT, int WT>
 __global__ __launch_bounds__(256) void w8a16_dequantize_kernel(const uint8_t* __restrict__ w,
                                                                const float* __restrict__ scales,
                                                                uint16_t* __restrict__ out, int N, int K,
@@ -130,14 +157,16 @@ __global__ __launch_bounds__(256) void w8a16_dequantize_kernel(const uint8_t* __
   const int n = (int)(e / K), k = (int)(e - (size_t)n * K);
   const float s = scales[(size_t)(n / block_n) * scale_cols + k / block_k];
   const uint32_t p = reinterpret_cast<const uint32_t*>(w)[vec];
-  const f32x2 lo = fp8x2_to_f32(p, false), hi = fp8x2_to_f32(p, true);
+  f32x2 lo, hi;
+  w4_to_f32<WT>(p, lo, hi);
+  const float b = WT == 1 ? 128.0f : 0.f;
   u32x2 o;
-  o.x = pack2<DT>(lo.x * s, lo.y * s);
-  o.y = pack2<DT>(hi.x * s, hi.y * s);
+  o.x = pack2<DT>((lo.x - b) * s, (lo.y - b) * s);
+  o.y = pack2<DT>((hi.x - b) * s, (hi.y - b) * s);
   reinterpret_cast<u32x2*>(out)[vec] = o;
 }
 
-template <typename DT>
+template <typename DT, int WT>
 static int launch_w8a16(const void* a, int lda, const void* w, const float* scales, const void* bias,
                         void* c, int M, int N, int K, int block_n, int block_k, hipStream_t stream) {
   const bool block_scale = block_k < K;
@@ -150,7 +179,7 @@ static int launch_w8a16(const void* a, int lda, const void* w, const float* scal
   while (rows_per_block > 8 && (N + rows_per_block - 1) / rows_per_block < 2048) rows_per_block >>= 1;
   dim3 grid((N + rows_per_block - 1) / rows_per_block, (M + MB - 1) / MB), block(256);
 #define MI355Q_W8(mb, bs)                                                                          \
-  hipLaunchKernelGGL((w8a16_skinny_kernel<DT, mb, bs>), grid, block, lds, stream,                  \
+  hipLaunchKernelGGL((w8a16_skinny_kernel<DT, mb, bs, WT>), grid, block, lds, stream,                  \
                      (const uint16_t*)a, lda, (const uint8_t*)w, scales, (const uint16_t*)bias,    \
                      (uint16_t*)c, M, N, K, block_scale ? block_n : 1, block_k, scale_cols,        \
                      rows_per_block)
@@ -185,9 +214,9 @@ static int check_w8_scales(const char* who, int N, int K, int block_n, int block
 
 using namespace mi355q;
 
-extern "C" int mi355q_w8a16_gemm(const void* a, int lda, const void* w, const float* scales,
-                                 const void* bias, void* c, int M, int N, int K, int block_n,
-                                 int block_k, int act_dtype, mi355q_stream_t stream) {
+static int w8_gemm_impl(int wt, const void* a, int lda, const void* w, const float* scales,
+                        const void* bias, void* c, int M, int N, int K, int block_n,
+                        int block_k, int act_dtype, mi355q_stream_t stream) {
   MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w8a16_gemm: dtype must be bf16 or fp16");
   if (M == 0) return MI355Q_OK;
   MI355Q_REQUIRE(a && w && scales && c && N > 0 && K > 0 && M >= 0, "w8a16_gemm: bad arguments");
@@ -196,14 +225,29 @@ extern "C" int mi355q_w8a16_gemm(const void* a, int lda, const void* w, const fl
   if (block_k <= 0 || block_k > K) block_k = K;
   if (block_n <= 0) block_n = 1;
   if (int st = check_w8_scales("w8a16_gemm", N, K, block_n, block_k)) return st;
-  if (act_dtype == MI355Q_BF16)
-    return launch_w8a16<BF16>(a, lda, w, scales, bias, c, M, N, K, block_n, block_k, (hipStream_t)stream);
-  return launch_w8a16<FP16>(a, lda, w, scales, bias, c, M, N, K, block_n, block_k, (hipStream_t)stream);
+  hipStream_t st_ = (hipStream_t)stream;
+  if (wt == 0) {
+    if (act_dtype == MI355Q_BF16) return launch_w8a16<BF16, 0>(a, lda, w, scales, bias, c, M, N, K, block_n, block_k, st_);
+    return launch_w8a16<FP16, 0>(a, lda, w, scales, bias, c, M, N, K, block_n, block_k, st_);
+  }
+  if (act_dtype == MI355Q_BF16) return launch_w8a16<BF16, 1>(a, lda, w, scales, bias, c, M, N, K, block_n, block_k, st_);
+  return launch_w8a16<FP16, 1>(a, lda, w, scales, bias, c, M, N, K, block_n, block_k, st_);
 }
 
-extern "C" int mi355q_w8a16_dequantize(const void* w, const float* scales, void* out, int N, int K,
-                                       int block_n, int block_k, int act_dtype,
-                                       mi355q_stream_t stream) {
+extern "C" int mi355q_w8a16_gemm(const void* a, int lda, const void* w, const float* scales,
+                                 const void* bias, void* c, int M, int N, int K, int block_n,
+                                 int block_k, int act_dtype, mi355q_stream_t stream) {
+  return w8_gemm_impl(0, a, lda, w, scales, bias, c, M, N, K, block_n, block_k, act_dtype, stream);
+}
+
+extern "C" int mi355q_wi8a16_gemm(const void* a, int lda, const void* w, const float* scales,
+                                  const void* bias, void* c, int M, int N, int K, int group_k,
+                                  int act_dtype, mi355q_stream_t stream) {
+  return w8_gemm_impl(1, a, lda, w, scales, bias, c, M, N, K, 1, group_k, act_dtype, stream);
+}
+
+static int w8_dequant_impl(int wt, const void* w, const float* scales, void* out, int N, int K,
+                           int block_n, int block_k, int act_dtype, mi355q_stream_t stream) {
   MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w8a16_dequantize: dtype must be bf16 or fp16");
   MI355Q_REQUIRE(w && scales && out && N > 0 && K > 0 && K % 16 == 0, "w8a16_dequantize: bad arguments");
   if (block_k <= 0 || block_k > K) block_k = K;
@@ -212,11 +256,22 @@ extern "C" int mi355q_w8a16_dequantize(const void* w, const float* scales, void*
   const int scale_cols = (K + block_k - 1) / block_k;
   const size_t total = (size_t)N * K / 4;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (act_dtype == MI355Q_BF16)
-    hipLaunchKernelGGL((w8a16_dequantize_kernel<BF16>), grid, block, 0, (hipStream_t)stream, (const uint8_t*)w,
-                       scales, (uint16_t*)out, N, K, block_n, block_k, scale_cols);
-  else
-    hipLaunchKernelGGL((w8a16_dequantize_kernel<FP16>), grid, block, 0, (hipStream_t)stream, (const uint8_t*)w,
-                       scales, (uint16_t*)out, N, K, block_n, block_k, scale_cols);
+#define MI355Q_DQ(DTT, WTT)                                                                                  \
+  hipLaunchKernelGGL((w8a16_dequantize_kernel<DTT, WTT>), grid, block, 0, (hipStream_t)stream, (const uint8_t*)w, \
+                     scales, (uint16_t*)out, N, K, block_n, block_k, scale_cols)
+  if (wt == 0) { if (act_dtype == MI355Q_BF16) MI355Q_DQ(BF16, 0); else MI355Q_DQ(FP16, 0); }
+  else { if (act_dtype == MI355Q_BF16) MI355Q_DQ(BF16, 1); else MI355Q_DQ(FP16, 1); }
+#undef MI355Q_DQ
   return check_launch("w8a16_dequantize_kernel");
+}
+
+extern "C" int mi355q_w8a16_dequantize(const void* w, const float* scales, void* out, int N, int K,
+                                       int block_n, int block_k, int act_dtype,
+                                       mi355q_stream_t stream) {
+  return w8_dequant_impl(0, w, scales, out, N, K, block_n, block_k, act_dtype, stream);
+}
+
+extern "C" int mi355q_wi8a16_dequantize(const void* w, const float* scales, void* out, int N, int K,
+                                        int group_k, int act_dtype, mi355q_stream_t stream) {
+  return w8_dequant_impl(1, w, scales, out, N, K, 1, group_k, act_dtype, stream);
 }

@@ -55,6 +55,8 @@ _SIGS = {
     "mi355q_moe_sum": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_w8a16_gemm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_w8a16_dequantize": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_wi8a16_gemm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_wi8a16_dequantize": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_linear_skinny": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_rms_norm": (c_int, [c_vp, c_vp, c_i64, c_vp, c_f32, c_int, c_int, c_int, c_vp]),
     "mi355q_fused_add_rms_norm": (c_int, [c_vp, c_i64, c_vp, c_vp, c_f32, c_int, c_int, c_int, c_vp]),

@@ -268,7 +268,7 @@ def gptq_gemm(a, b_q_weight: PackedW4, b_gptq_qzeros, b_gptq_scales, b_g_idx, us
     travel inside it; g_idx must be empty here -- checkpoints with activation reordering are served
     one level up (MI355XW4A16LinearKernel sorts the rows at load time and gathers the inputs)."""
     if bit != 4:
-        raise RuntimeError(f"gptq_gemm: {bit}-bit weights are not supported")
+        raise RuntimeError(f"gptq_gemm: {bit}-bit weights go through wi8a16_gemm (8 bits) or are not supported")
     if b_g_idx is not None and b_g_idx.numel() > 0:
         raise RuntimeError("gptq_gemm: pass activation-reordered layers through MI355XW4A16LinearKernel (g_idx must be empty here)")
     return w4a16_gemm(a, b_q_weight)
@@ -441,6 +441,63 @@ def w8a16_gemm(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, bloc
     out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     check(_lib.lib().mi355q_w8a16_gemm(x2.data_ptr(), x2.stride(0), weight.data_ptr(), scales.data_ptr(), _ptr(bias),
                                        out.data_ptr(), M, N, K, bn, bk, _dt(x), _stream()))
+    return out.reshape(x.shape[:-1] + (N,))
+
+
+# ---------------------------------------------------------------------------
+# 8-bit integer weights (GPTQ 8 bits, symmetric)
+# ---------------------------------------------------------------------------
+def gptq8_repack(qweight: torch.Tensor, scales: torch.Tensor, group_size: int):
+    """GPTQ 8-bit checkpoint tensors -> kernel operands.  qweight int32 [K/4, N] (four consecutive k
+    per word, least significant byte first; auto_gptq.py:381-445 with pack_factor 4), scales
+    [K/G, N] -> (uint8 [N, K] values still biased by 128, fp32 [N, K/G] scales)."""
+    if qweight.dtype != torch.int32 or qweight.dim() != 2:
+        raise RuntimeError("gptq8 qweight must be int32 [K/4, N]")
+    K4, N = qweight.shape
+    K = 4 * K4
+    G = K if group_size in (-1, 0) else group_size
+    if K % G or G % 16 or scales.shape != (K // G, N):
+        raise RuntimeError(f"gptq8: scales shape {tuple(scales.shape)} / group size {G} do not fit K={K}, N={N}")
+    w = qweight.contiguous().view(torch.uint8).view(K4, N, 4).permute(1, 0, 2).reshape(N, K).contiguous()
+    return w, scales.t().to(torch.float32).contiguous()
+
+
+def wi8a16_dequantize(weight: torch.Tensor, scales: torch.Tensor, group_size: int, dtype: torch.dtype) -> torch.Tensor:
+    """[N, K] 16-bit weight = round((q - 128) * scale): the reference's reconstruct route for 8-bit
+    GPTQ (q_gemm.cu:1509-1522)."""
+    _need_cuda(weight, scales)
+    N, K = weight.shape
+    G = K if group_size in (-1, 0) else group_size
+    if weight.dtype != torch.uint8 or scales.dtype != torch.float32 or scales.shape != (N, K // G):
+        raise RuntimeError("wi8a16: weight must be uint8 [N, K] and scales fp32 [N, K/G]")
+    out = torch.empty((N, K), dtype=dtype, device=weight.device)
+    check(_lib.lib().mi355q_wi8a16_dequantize(weight.data_ptr(), scales.data_ptr(), out.data_ptr(), N, K, G,
+                                              _DT[dtype], _stream()))
+    return out
+
+
+def wi8a16_gemm(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, group_size: int,
+                bias: torch.Tensor | None = None) -> torch.Tensor:
+    """x[..., K] @ ((weight[N, K] - 128) * scales)^T (+ bias): ops.gptq_gemm with bit = 8
+    (vllm/_custom_ops.py:558-577).  Operands from `gptq8_repack`."""
+    _need_cuda(x, weight, scales)
+    N, K = weight.shape
+    G = K if group_size in (-1, 0) else group_size
+    if weight.dtype != torch.uint8 or scales.dtype != torch.float32 or scales.shape != (N, K // G) or \
+            not scales.is_contiguous() or not weight.is_contiguous():
+        raise RuntimeError("wi8a16: weight must be contiguous uint8 [N, K] and scales contiguous fp32 [N, K/G]")
+    if x.shape[-1] != K:
+        raise RuntimeError(f"input feature size {x.shape[-1]} != {K}")
+    x2 = x.reshape(-1, K)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if M > DEQUANT_MATMUL_MIN_TOKENS and not torch.cuda.is_current_stream_capturing():
+        out = torch.nn.functional.linear(x2, wi8a16_dequantize(weight, scales, G, x.dtype), bias)
+        return out.reshape(x.shape[:-1] + (N,))
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(_lib.lib().mi355q_wi8a16_gemm(x2.data_ptr(), x2.stride(0), weight.data_ptr(), scales.data_ptr(), _ptr(bias),
+                                        out.data_ptr(), M, N, K, G, _dt(x), _stream()))
     return out.reshape(x.shape[:-1] + (N,))
 
 

@@ -11,7 +11,7 @@ from .fp8 import Fp8Config, Fp8LinearMethod
 from .gptq import AutoGPTQConfig, AutoGPTQLinearMethod
 from .inc import INCConfig, INCLayerConfig, INCLinearMethod, INCWna16Scheme, resolve_scheme
 from .moe import FusedMoE, MoeWNA16Config, MoeWNA16Method, fused_experts, fused_topk
-from .mp_kernel import (MI355XW4A16LinearKernel, MPLinearKernel, MPLinearLayerConfig, choose_mp_linear_kernel,
+from .mp_kernel import (MI355XW4A16LinearKernel, MI355XW8A16LinearKernel, MPLinearKernel, MPLinearLayerConfig, choose_mp_linear_kernel,
                         register_linear_kernel)
 from .registry import (QUANTIZATION_METHODS, QuantizationConfig, QuantizeMethodBase, get_quantization_config,
                        register_quantization_config, resolve_quantization)

@@ -193,7 +193,7 @@ class INCLinearMethod(LinearMethodBase):
 class INCWNA16LinearScheme(INCLinearScheme):
     """schemes/inc_wna16_linear.py:28-160: the layer becomes an AutoGPTQ or AutoAWQ layer.  Where the
     reference first asks whether Marlin can take the layer, this build has one kernel family for
-    both layouts; what it cannot run (other than 4 bits, asymmetric GPTQ packing) is refused here
+    both layouts; what it cannot run (2 / 3 bits, asymmetric GPTQ packing, 8-bit AWQ) is refused here
     with the reference's wording."""
 
     def __init__(self, layer_config: INCLayerConfig) -> None:
@@ -207,10 +207,10 @@ class INCWNA16LinearScheme(INCLinearScheme):
     def _build_inner_method(self):
         lc = self.layer_config
         if lc.is_gptq:
-            if (lc.bits, lc.sym) != (4, True):
+            if (lc.bits, lc.sym) not in ((4, True), (8, True)):
                 raise NotImplementedError(
                     f"INC quantization with bits={lc.bits}, sym={lc.sym} is not supported. "
-                    "Only 4-bit symmetric quantization is supported with the MI355X kernels.")
+                    "Only 4-bit and 8-bit symmetric quantization is supported with the MI355X kernels.")
             return AutoGPTQLinearMethod(AutoGPTQConfig(weight_bits=lc.bits, group_size=lc.group_size, desc_act=False,
                                                        is_sym=lc.sym, lm_head_quantized=False, dynamic={},
                                                        full_config={}))

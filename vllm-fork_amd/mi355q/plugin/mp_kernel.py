@@ -216,6 +216,57 @@ class MI355XW4A16LinearKernel(MPLinearKernel):
         return ops.w4a16_gemm_add_rms_norm(x, residual, norm_weight, epsilon, layer.mi355q_weight, bias=bias)
 
 
+class MI355XW8A16LinearKernel(MPLinearKernel):
+    """8-bit symmetric integer weights (GPTQ 8 bits, uint8b128) x 16-bit activations on gfx950.
+
+    After process_weights_after_loading the layer holds <w_q> as uint8 [N, K] (values biased by 128)
+    and <w_s> as fp32 [N, K/G].  Checkpoint layout: weight int32 [K/4, N] packed along K, scales
+    [K/G, N].  Activation reordering is not served (8-bit checkpoints with desc_act are refused)."""
+
+    @classmethod
+    def get_min_capability(cls) -> int:
+        return 95
+
+    @classmethod
+    def can_implement(cls, c: MPLinearLayerConfig) -> tuple[bool, str | None]:
+        if c.weight_type != scalar_types.uint8b128:
+            return False, f"Quant type {c.weight_type} not supported; supported: [{scalar_types.uint8b128}]"
+        if c.act_type not in (torch.float16, torch.bfloat16):
+            return False, "Only float16/bfloat16 activations are supported"
+        if c.zero_points:
+            return False, "8-bit weights with zero points are not supported"
+        if c.has_g_idx:
+            return False, "Activation reordering (g_idx) is not supported for 8-bit weights"
+        K, N = c.partition_weight_shape
+        G = K if c.group_size == -1 else c.group_size
+        if G <= 0 or K % G or G % 16 or K % 16:
+            return False, f"Input features {K} / group size {G} must be multiples of 16 and divide"
+        return True, None
+
+    def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
+        c = self.config
+        K, N = c.partition_weight_shape
+        G = K if c.group_size == -1 else c.group_size
+        w_q, w_s, _, _ = self._get_weight_params(layer)
+        if tuple(w_q.shape) != (K // 4, N):
+            raise ValueError(f"{self.w_q_name}: shape {tuple(w_q.shape)} != ({K // 4}, {N})")
+        w, s = ops.gptq8_repack(w_q.data, w_s.data, G)
+        _set_param(layer, self.w_q_name, w)
+        _set_param(layer, self.w_s_name, s)
+        if self.w_zp_name is not None:
+            _set_param(layer, self.w_zp_name, None)
+        if self.w_gidx_name is not None:
+            _set_param(layer, self.w_gidx_name, None)
+        layer.mi355q_group = G
+
+    def apply_weights(self, layer, x, bias=None):
+        out = ops.wi8a16_gemm(x, getattr(layer, self.w_q_name).data, getattr(layer, self.w_s_name).data,
+                              layer.mi355q_group)
+        if bias is not None:
+            out.add_(bias)     # on the rounded product, as the reference's output.add_(bias)
+        return out
+
+
 def _act_order_perm(g_idx: torch.Tensor | None, K: int, G: int) -> torch.Tensor | None:
     """Row order that sorts a GPTQ g_idx by group (stable), or None when the rows already are in
     group order (checkpoints written without activation reordering carry a trivial or empty g_idx)."""
@@ -247,7 +298,8 @@ def _permute_packed_rows(qweight: torch.Tensor, perm: torch.Tensor) -> torch.Ten
 
 
 # platform name -> ordered kernel classes.  "rocm" is the only platform this package serves.
-_POSSIBLE_KERNELS: dict[str, list[type[MPLinearKernel]]] = {"rocm": [MI355XW4A16LinearKernel]}
+_POSSIBLE_KERNELS: dict[str, list[type[MPLinearKernel]]] = {"rocm": [MI355XW4A16LinearKernel,
+                                                                  MI355XW8A16LinearKernel]}
 
 
 def register_linear_kernel(kernel_class: type, platform: str = "rocm", kernel_type: str = "mp") -> None:
