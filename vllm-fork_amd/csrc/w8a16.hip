@@ -10,6 +10,9 @@
 // The same kernels serve 8-bit integer weights stored as bytes biased by 128 (GPTQ's uint8b128:
 // w = (q - 128) * scale): WT = 1 converts with v_cvt_f32_ubyte and takes the bias out through the
 // sum of the lane's activations, so the inner loop stays one convert + one fma per weight.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mi355q {
@@ -144,6 +147,123 @@ __global__ __launch_bounds__(256) void w8a16_skinny_kernel(
   }
 }
 
+// 16 8-bit weights (one u32x4, consecutive k of one output channel) -> two MFMA operand fragments
+// of 8 16-bit values each (k 0..7 and k 8..15).  fp8 values and the raw bytes 0..255 are exactly
+// representable in both activation dtypes, so nothing is rounded here (the bias of 128 of the
+// integer format is taken out afterwards through the sum of the activations).
+template <typename DT, int WT>
+__device__ inline void w16_to_frags(u32x4 w, u32x4& f0, u32x4& f1) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    f32x2 lo, hi;
+    w4_to_f32<WT>(w[e], lo, hi);
+    uint32_t a, b;
+    if constexpr (DT::id == MI355Q_BF16) {   // exact: the upper halves of the fp32 words
+      a = (__float_as_uint(lo.x) >> 16) | (__float_as_uint(lo.y) & 0xffff0000u);
+      b = (__float_as_uint(hi.x) >> 16) | (__float_as_uint(hi.y) & 0xffff0000u);
+    } else {
+      a = pack2<DT>(lo.x, lo.y);
+      b = pack2<DT>(hi.x, hi.y);
+    }
+    if (e < 2) { f0[2 * e] = a; f0[2 * e + 1] = b; }
+    else { f1[2 * e - 4] = a; f1[2 * e - 3] = b; }
+  }
+}
+
+// 2..16 activation rows per pass: a workgroup owns 16 output channels and its waves split K.  Lane
+// (kq, ml) loads the 16 weights k0 + 16 kq .. of channel n0 + ml (one 16-byte load per 64 k),
+// expands them once into two MFMA A-operand fragments, and the activation rows come from LDS as B
+// operands with the matching k order, so the cost per weight byte does not grow with the row count.
+// Block scales are applied to the group's partial sums in fp32; the waves' sums meet in LDS;
+// per-channel scales and the bias at the end, one rounding.
+template <typename DT, bool BLOCK_SCALE, int WT>
+__global__ __launch_bounds__(512) void w8a16_mfma_kernel(
+    const uint16_t* __restrict__ a, int lda, const uint8_t* __restrict__ w,
+    const float* __restrict__ scales, const uint16_t* __restrict__ bias, uint16_t* __restrict__ c,
+    int M, int N, int K, int block_n, int block_k, int scale_cols, int rows_pp, int nw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);                            // [nw][16 rows][16 channels]
+  float* sc_l = red + (size_t)nw * 256;                                   // [16 channels][scale_cols] (block scales)
+  const int sc_pad = BLOCK_SCALE ? (16 * scale_cols + 3) & ~3 : 0;
+  uint16_t* xs = reinterpret_cast<uint16_t*>(sc_l + sc_pad);              // [rows_pp][K + 8]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kq = lane >> 4, ml = lane & 15;
+  const int nthreads = nw * 64;
+  const int m0 = blockIdx.y * rows_pp;
+  const int mb = min(rows_pp, M - m0);
+  const int kv = K >> 3, astride = K + 8;
+  for (int idx = threadIdx.x; idx < mb * kv; idx += nthreads) {
+    const int m = idx / kv, v = idx - m * kv;
+    *reinterpret_cast<u32x4*>(xs + (size_t)m * astride + 8 * v) =
+        *reinterpret_cast<const u32x4*>(a + (size_t)(m0 + m) * lda + 8 * v);
+  }
+  const int n0 = blockIdx.x * 16;
+  if (BLOCK_SCALE) {   // the scales of the workgroup's channels wait in LDS: a flush must not wait for memory
+    for (int idx = threadIdx.x; idx < 16 * scale_cols; idx += nthreads) {
+      const int nl = idx / scale_cols, kb = idx - nl * scale_cols;
+      sc_l[idx] = scales[(size_t)(min(n0 + nl, N - 1) / block_n) * scale_cols + kb];
+    }
+  }
+  __syncthreads();
+  const int kw = K / nw, kbeg = wave * kw, kend = kbeg + kw;   // this wave's slice: whole 64-k steps
+  const uint8_t* wrow = w + (size_t)min(n0 + ml, N - 1) * K + 16 * kq;
+  const uint16_t* arow = xs + (size_t)min(ml, mb - 1) * astride + 16 * kq;
+  f32x4 tot = f32x4{0.f, 0.f, 0.f, 0.f}, acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this lane's outputs: activation row ml, channels n0 + 4 kq + r
+  const float* srow = sc_l + (size_t)(4 * kq) * scale_cols;
+  // WT == 1: acc1 = sum of the activations of the group (all-ones A operand), acc - 128 acc1 = sum a (q - 128)
+  f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
+  auto centred = [&]() {
+    if constexpr (WT == 1) return acc - 128.0f * acc1;
+    else return acc;
+  };
+  auto flush = [&](int kb) {
+    const f32x4 d = centred();
+#pragma unroll
+    for (int r = 0; r < 4; r++) tot[r] = __builtin_fmaf(srow[r * scale_cols + kb], d[r], tot[r]);
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  int k0 = kbeg;
+  for (; k0 + 256 <= kend; k0 += 256) {
+    u32x4 wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) wv[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + k0 + 64 * j));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      u32x4 f0, f1;
+      w16_to_frags<DT, WT>(wv[j], f0, f1);
+      const uint16_t* ap = arow + k0 + 64 * j;
+      const u32x4 b0 = *reinterpret_cast<const u32x4*>(ap), b1 = *reinterpret_cast<const u32x4*>(ap + 8);
+      acc = mfma16<DT>(f0, b0, acc);
+      acc = mfma16<DT>(f1, b1, acc);
+      if constexpr (WT == 1) { acc1 = mfma16<DT>(ones, b0, acc1); acc1 = mfma16<DT>(ones, b1, acc1); }
+      if (BLOCK_SCALE && (k0 + 64 * j + 64) % block_k == 0) flush((k0 + 64 * j) / block_k);
+    }
+  }
+  for (; k0 < kend; k0 += 64) {
+    u32x4 f0, f1;
+    w16_to_frags<DT, WT>(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + k0)), f0, f1);
+    const u32x4 b0 = *reinterpret_cast<const u32x4*>(arow + k0), b1 = *reinterpret_cast<const u32x4*>(arow + k0 + 8);
+    acc = mfma16<DT>(f0, b0, acc);
+    acc = mfma16<DT>(f1, b1, acc);
+    if constexpr (WT == 1) { acc1 = mfma16<DT>(ones, b0, acc1); acc1 = mfma16<DT>(ones, b1, acc1); }
+    if (BLOCK_SCALE && (k0 + 64) % block_k == 0) flush(k0 / block_k);
+  }
+  if (BLOCK_SCALE && kend % block_k != 0) flush((kend - 1) / block_k);   // a scale block the slice ends inside
+  *reinterpret_cast<f32x4*>(red + ((size_t)wave * 16 + ml) * 16 + 4 * kq) = BLOCK_SCALE ? tot : centred();
+  __syncthreads();
+  for (int it = threadIdx.x; it < mb * 16; it += nthreads) {
+    const int m = it >> 4, nl = it & 15, n = n0 + nl;
+    if (n >= N) continue;
+    float v = 0.f;
+    for (int i = 0; i < nw; i++) v += red[((size_t)i * 16 + m) * 16 + nl];
+    if (!BLOCK_SCALE) v *= scales[n];
+    c[(size_t)(m0 + m) * N + n] = DT::from_f32(v + (bias ? DT::to_f32(bias[n]) : 0.f));
+  }
+}
+
 // W16[N,K] = round(fp8(W) * scale): the weight the dense-GEMM route multiplies with.
 template <typename DT, int WT>
 __global__ __launch_bounds__(256) void w8a16_dequantize_kernel(const uint8_t* __restrict__ w,
@@ -171,6 +291,27 @@ static int launch_w8a16(const void* a, int lda, const void* w, const float* scal
                         void* c, int M, int N, int K, int block_n, int block_k, hipStream_t stream) {
   const bool block_scale = block_k < K;
   const int scale_cols = block_scale ? (K + block_k - 1) / block_k : 1;
+  // several rows: matrix cores (whole 64-k steps per wave; scale blocks must end on 64-k steps)
+  if (M >= 2 && K % 64 == 0 && (!block_scale || block_k % 64 == 0) && !getenv("MI355Q_W8_NO_MFMA")) {
+    int nw = 8;
+    while (nw > 1 && K % (64 * nw)) nw >>= 1;
+    int rows_pp = std::min(M, 16);
+    const size_t red_bytes = (size_t)nw * 1024 + (block_scale ? (size_t)((16 * scale_cols + 3) & ~3) * 4 : 0);
+    while (rows_pp > 1 && red_bytes + (size_t)rows_pp * (K + 8) * 2 > 144 * 1024) rows_pp--;
+    const size_t lds_m = red_bytes + (size_t)rows_pp * (K + 8) * 2;
+    if (lds_m <= 144 * 1024) {
+      dim3 grid((N + 15) / 16, (M + rows_pp - 1) / rows_pp), block(nw * 64);
+      if (block_scale)
+        hipLaunchKernelGGL((w8a16_mfma_kernel<DT, true, WT>), grid, block, lds_m, stream, (const uint16_t*)a, lda,
+                           (const uint8_t*)w, scales, (const uint16_t*)bias, (uint16_t*)c, M, N, K, block_n, block_k,
+                           scale_cols, rows_pp, nw);
+      else
+        hipLaunchKernelGGL((w8a16_mfma_kernel<DT, false, WT>), grid, block, lds_m, stream, (const uint16_t*)a, lda,
+                           (const uint8_t*)w, scales, (const uint16_t*)bias, (uint16_t*)c, M, N, K, 1, block_k,
+                           scale_cols, rows_pp, nw);
+      return check_launch("w8a16_mfma_kernel");
+    }
+  }
   int MB = M >= 4 ? 4 : (M >= 2 ? 2 : 1);
   while (MB > 1 && (size_t)MB * K * 2 > 64 * 1024) MB >>= 1;
   const size_t lds = (size_t)MB * K * 2;
