@@ -1593,12 +1593,19 @@ __global__ __launch_bounds__(256) void w4a16_mm_kernel(const MmParams p) {
 
   for (int c = c0; c < c1; c++) {
     const int cur = (c - c0) & 1;
-    const bool more = c + 1 < c1;
-    if (more) {
-      load_w(c + 1, wn);
-      load_s(c + 1, sn, zn);
-      load_acts(c + 1, an);
-    }
+    // The next chunk's operands are requested unconditionally (the last iteration re-requests its own
+    // chunk): with the loads behind a branch the compiler cannot count what is outstanding and waits
+    // for all of it at the first consumer, which exposes a whole memory round trip in every chunk.
+    const int cn = min(c + 1, c1 - 1);
+    load_w(cn, wn);
+    load_s(cn, sn, zn);
+    // ... and they must be ISSUED here: left alone, the scheduler sinks them below the arithmetic
+    // (shorter live ranges), where the next iteration then waits for them at once.  The 112-wide
+    // strips have no registers left for the activation chunk as well: there only the weights (the
+    // HBM round trip) are pinned, the activations (an L2 round trip) may sink.
+    if constexpr (NS == 7) __builtin_amdgcn_sched_barrier(0);
+    load_acts(cn, an);
+    if constexpr (NS != 7) __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[RT][CT], acc1[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
@@ -1638,11 +1645,9 @@ __global__ __launch_bounds__(256) void w4a16_mm_kernel(const MmParams p) {
           tot[rt][ct][r] = __builtin_fmaf(s, __builtin_fmaf(-z, acc1[rt][r], acc[rt][ct][r]), tot[rt][ct][r]);
       }
     }
-    if (more) {
-      store_acts(cur ^ 1, an);
+    store_acts(cur ^ 1, an);
 #pragma unroll
-      for (int i = 0; i < CT; i++) { wc[i] = wn[i]; sc[i] = sn[i]; if constexpr (HAS_ZC) zv[i] = zn[i]; }
-    }
+    for (int i = 0; i < CT; i++) { wc[i] = wn[i]; sc[i] = sn[i]; if constexpr (HAS_ZC) zv[i] = zn[i]; }
     __syncthreads();
   }
 

@@ -104,7 +104,7 @@ DEQUANT_MATMUL_MIN_TOKENS = 32
 # token range served by the tiled matrix-core W4A16 kernel (below: the decode kernels; above: dequantise
 # once + dense GEMM, compute-bound and best left to the BLAS)
 MM_MIN_TOKENS = 17
-MM_MAX_TOKENS = 512
+MM_MAX_TOKENS = 768
 
 
 COUNTER_BYTES = 64 * 1024   # arrival counters at the head of the workspace; partial tiles follow
