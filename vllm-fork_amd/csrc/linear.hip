@@ -105,10 +105,25 @@ __global__ __launch_bounds__(512) void linear_mfma_kernel(const uint16_t* __rest
   const int m0 = blockIdx.y * rows_pp;
   const int mb = min(rows_pp, M - m0);
   const int kv = K >> 3, astride = K + 8;
-  for (int idx = threadIdx.x; idx < mb * kv; idx += 512) {
-    const int m = idx / kv, v = idx - m * kv;
-    *reinterpret_cast<u32x4*>(xs + (size_t)m * astride + 8 * v) =
-        *reinterpret_cast<const u32x4*>(a + (size_t)(m0 + m) * lda + 8 * v);
+  // four requests in flight per thread: one at a time would pay an L2 round trip per iteration
+  for (int base = threadIdx.x; base < mb * kv; base += 4 * 512) {
+    u32x4 t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int idx = base + j * 512;
+      if (idx < mb * kv) {
+        const int m = idx / kv, v = idx - m * kv;
+        t[j] = *reinterpret_cast<const u32x4*>(a + (size_t)(m0 + m) * lda + 8 * v);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int idx = base + j * 512;
+      if (idx < mb * kv) {
+        const int m = idx / kv, v = idx - m * kv;
+        *reinterpret_cast<u32x4*>(xs + (size_t)m * astride + 8 * v) = t[j];
+      }
+    }
   }
   __syncthreads();
   const int n_begin = blockIdx.x * rows_per_block;
@@ -118,15 +133,32 @@ __global__ __launch_bounds__(512) void linear_mfma_kernel(const uint16_t* __rest
     const uint16_t* wrow = w + (size_t)min(n0 + ml, N - 1) * K + 8 * kq;
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
     int k0 = 0;
-    for (; k0 + 256 <= K; k0 += 256) {
-      u32x4 wf[8];
+    // the next 256 k of weights are requested before the current ones are multiplied (two register
+    // sets); the scheduling barrier keeps the requests ahead of the arithmetic
+    u32x4 wf[8], wnx[8];
+    if (K >= 256) {
 #pragma unroll
-      for (int j = 0; j < 8; j++) wf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + k0 + 32 * j));
+      for (int j = 0; j < 8; j++) wf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + 32 * j));
+    }
+    for (; k0 + 512 <= K; k0 += 256) {   // every block but the last: request the next one first
+#pragma unroll
+      for (int j = 0; j < 8; j++) wnx[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + k0 + 256 + 32 * j));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 8; j += 2) {
         acc0 = mfma16<DT>(wf[j], *reinterpret_cast<const u32x4*>(arow + k0 + 32 * j), acc0);
         acc1 = mfma16<DT>(wf[j + 1], *reinterpret_cast<const u32x4*>(arow + k0 + 32 * j + 32), acc1);
       }
+#pragma unroll
+      for (int j = 0; j < 8; j++) wf[j] = wnx[j];
+    }
+    if (k0 + 256 <= K) {                 // the last whole block
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        acc0 = mfma16<DT>(wf[j], *reinterpret_cast<const u32x4*>(arow + k0 + 32 * j), acc0);
+        acc1 = mfma16<DT>(wf[j + 1], *reinterpret_cast<const u32x4*>(arow + k0 + 32 * j + 32), acc1);
+      }
+      k0 += 256;
     }
     for (; k0 < K; k0 += 32)
       acc0 = mfma16<DT>(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + k0)),

@@ -192,10 +192,25 @@ __global__ __launch_bounds__(512) void w8a16_mfma_kernel(
   const int m0 = blockIdx.y * rows_pp;
   const int mb = min(rows_pp, M - m0);
   const int kv = K >> 3, astride = K + 8;
-  for (int idx = threadIdx.x; idx < mb * kv; idx += nthreads) {
-    const int m = idx / kv, v = idx - m * kv;
-    *reinterpret_cast<u32x4*>(xs + (size_t)m * astride + 8 * v) =
-        *reinterpret_cast<const u32x4*>(a + (size_t)(m0 + m) * lda + 8 * v);
+  // four requests in flight per thread: one at a time would pay an L2 round trip per iteration
+  for (int base = threadIdx.x; base < mb * kv; base += 4 * nthreads) {
+    u32x4 t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int idx = base + j * nthreads;
+      if (idx < mb * kv) {
+        const int m = idx / kv, v = idx - m * kv;
+        t[j] = *reinterpret_cast<const u32x4*>(a + (size_t)(m0 + m) * lda + 8 * v);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int idx = base + j * nthreads;
+      if (idx < mb * kv) {
+        const int m = idx / kv, v = idx - m * kv;
+        *reinterpret_cast<u32x4*>(xs + (size_t)m * astride + 8 * v) = t[j];
+      }
+    }
   }
   const int n0 = blockIdx.x * 16;
   if (BLOCK_SCALE) {   // the scales of the workgroup's channels wait in LDS: a flush must not wait for memory
