@@ -269,6 +269,15 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const PAParams p) 
   }
 
   if constexpr (FUSED) {
+    // The new token's raw values are first touched HERE, after every cache read has been requested:
+    // otherwise the compiler converts them right behind their loads and the wait for that round
+    // trip lands in front of the K/V requests (loads return in order, so waiting for these older
+    // ones here leaves the K/V reads in flight).
+    {
+      uint32_t t0 = nk_x, t1 = nk_y, t2 = nk_c, t3 = nk_s, t4 = nv;
+      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4));
+      nk_x = (uint16_t)t0; nk_y = (uint16_t)t1; nk_c = (uint16_t)t2; nk_s = (uint16_t)t3; nv = (uint16_t)t4;
+    }
     // RoPE on the query fragments: the partner d + HEAD/2 of every element sits in fragment
     // ds + DS/2 of the same lane
 #pragma unroll
