@@ -468,3 +468,148 @@ def test_fused_moe_layer_awq_checkpoint():
     w, ids = moe_ref.route(logits, topk, renormalize=True)
     ref = moe_ref.moe(x, packed(("w1", "w3")), packed(("w2",)), w, ids, G)
     np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=2e-3)
+
+
+# -- compressed-tensors checkpoints -------------------------------------------------------------------
+_CT_FUSED = {"qkv_proj": ["q_proj", "k_proj", "v_proj"], "gate_up_proj": ["gate_proj", "up_proj"]}
+
+
+def _ct_config(fmt="pack-quantized", **weights):
+    from mi355q.plugin import CompressedTensorsConfig
+    w = {"num_bits": 4, "type": "int", "symmetric": True, "strategy": "group", "group_size": 128, "dynamic": False}
+    w.update(weights)
+    cfg = CompressedTensorsConfig.from_config({
+        "quant_method": "compressed-tensors", "format": fmt, "ignore": ["lm_head"],
+        "config_groups": {"group_0": {"targets": ["Linear"], "weights": w, "input_activations": None}}})
+    cfg.packed_modules_mapping = _CT_FUSED
+    return cfg
+
+
+@pytest.mark.parametrize("sym", [True, False])
+def test_compressed_tensors_w4a16_checkpoint(sym):
+    """pack-quantized INT4: weight_packed int32 [N, K/8] (8 consecutive k per word), weight_scale [N, K/G],
+    weight_zero_point int32 [N/8, K/G] (8 consecutive n per word).  Same unsigned values as a GPTQ
+    checkpoint, so the oracle's GPTQ-layout GEMM over the transposed tensors is the expected result."""
+    rng = np.random.default_rng(21 + sym)
+    hidden, inter, G, T = 512, 1024, 128, 3
+    cfg = _ct_config(symmetric=sym)
+    with torch.device(DEV):
+        gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16,
+                                        quant_config=cfg, prefix="model.layers.0.mlp.gate_up_proj", return_bias=False)
+    qs, ss, zs = [], [], []
+    for i in range(2):
+        q = rng.integers(0, 16, size=(hidden, inter), dtype=np.int32)
+        s = orc.f32_to_h16((0.02 * rng.random((hidden // G, inter)) + 0.005).astype(np.float32))
+        gu.weight_loader(gu.weight_packed, torch.from_numpy(np.ascontiguousarray(orc.gptq_pack(q).T)), i)
+        gu.weight_loader(gu.weight_scale, to_dev(np.ascontiguousarray(s.T)).cpu(), i)
+        gu.weight_loader(gu.weight_shape, torch.tensor([inter, hidden]), i)
+        if not sym:
+            z = rng.integers(0, 16, size=(hidden // G, inter), dtype=np.int32)
+            gu.weight_loader(gu.weight_zero_point, torch.from_numpy(np.ascontiguousarray(orc.pack_cols(z).T)), i)
+            zs.append(z)
+        qs.append(q)
+        ss.append(s)
+    gu.process_weights_after_loading()
+    q, s = np.concatenate(qs, axis=1), np.concatenate(ss, axis=1)
+    x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    if sym:
+        ref = orc.w4a16_gemm(x, orc.gptq_pack(q), s, None, None, G=G)
+    else:
+        ref = orc.w4a16_gemm(x, orc.gptq_pack(q), s, orc.pack_cols(np.concatenate(zs, axis=1)), None, G=G,
+                             zp_mode=orc.ZP_NSEQ)
+    got = gu(to_dev(x))
+    np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=2e-2)
+    assert (to_bits(got) == ref).mean() > 0.97
+
+
+def test_compressed_tensors_w8a16_int_channelwise_and_grouped():
+    """pack-quantized INT8 (uint8b128): weight_packed int32 [N, K/4]; channel strategy has weight_scale [N, 1]."""
+    rng = np.random.default_rng(23)
+    hidden, out_f, T = 1024, 768, 3
+    for G, weights in ((hidden, {"num_bits": 8, "strategy": "channel", "group_size": None}),
+                       (128, {"num_bits": 8})):
+        cfg = _ct_config(**weights)
+        with torch.device(DEV):
+            lin = RowParallelLinear(hidden, out_f, bias=True, params_dtype=torch.bfloat16, quant_config=cfg,
+                                    prefix="model.layers.0.mlp.down_proj", return_bias=False)
+        assert type(lin.scheme.kernel).__name__ == "MI355XW8A16LinearKernel"
+        q = rng.integers(0, 256, size=(hidden, out_f), dtype=np.int32)
+        s = orc.f32_to_h16((0.004 * rng.random((hidden // G, out_f)) + 0.001).astype(np.float32))
+        bias = orc.f32_to_h16(rng.standard_normal(out_f).astype(np.float32))
+        lin.weight_loader(lin.weight_packed, torch.from_numpy(np.ascontiguousarray(orc.gptq8_pack(q).T)))
+        lin.weight_loader(lin.weight_scale, to_dev(np.ascontiguousarray(s.T)).cpu())
+        lin.weight_loader(lin.bias, to_dev(bias).cpu())
+        lin.process_weights_after_loading()
+        x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+        ref = orc.gptq8_gemm(x, q, s, G, bias)
+        got = lin(to_dev(x))
+        np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=1e-2)
+        assert (to_bits(got) == ref).mean() > 0.97
+
+
+def test_compressed_tensors_actorder_group():
+    """actorder "group": weight_g_idx[k] names the scale group of input feature k;
+    W[k, n] = (q[k, n] - 8) * s[g_idx[k], n], computed directly."""
+    rng = np.random.default_rng(24)
+    hidden, out_f, G, T = 1024, 512, 128, 4
+    cfg = _ct_config(actorder="group")
+    with torch.device(DEV):
+        lin = RowParallelLinear(hidden, out_f, bias=False, params_dtype=torch.bfloat16, quant_config=cfg,
+                                prefix="model.layers.0.mlp.down_proj", return_bias=False)
+    q = rng.integers(0, 16, size=(hidden, out_f), dtype=np.int32)
+    s = orc.f32_to_h16((0.02 * rng.random((hidden // G, out_f)) + 0.005).astype(np.float32))
+    g_idx = rng.permutation(np.arange(hidden) // G).astype(np.int32)
+    lin.weight_loader(lin.weight_packed, torch.from_numpy(np.ascontiguousarray(orc.gptq_pack(q).T)))
+    lin.weight_loader(lin.weight_scale, to_dev(np.ascontiguousarray(s.T)).cpu())
+    lin.weight_loader(lin.weight_g_idx, torch.from_numpy(g_idx))
+    lin.process_weights_after_loading()
+    assert lin.mi355q_perm is not None
+    x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    W = (q - 8).astype(np.float64) * f32(s)[g_idx].astype(np.float64)
+    ref = f32(x).astype(np.float64) @ W
+    np.testing.assert_allclose(f32(to_bits(lin(to_dev(x)))), ref, rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("strategy", ["tensor", "channel", "block"])
+def test_compressed_tensors_fp8_weight_only(strategy):
+    """float-quantized fp8 weights (a W8A8 checkpoint with dynamic activation arguments included): served
+    weight-only, x @ (fp8(w) * scale)^T."""
+    from mi355q.plugin import CompressedTensorsConfig
+    rng = np.random.default_rng(25)
+    hidden, inter, T = 512, 768, 2
+    w_args = {"num_bits": 8, "type": "float", "symmetric": True, "strategy": strategy, "dynamic": False}
+    if strategy == "block":
+        w_args["block_structure"] = [128, 128]
+    act = {"num_bits": 8, "type": "float", "symmetric": True, "strategy": "token", "dynamic": True}
+    cfg = CompressedTensorsConfig.from_config({
+        "quant_method": "compressed-tensors", "format": "float-quantized", "ignore": ["lm_head"],
+        "config_groups": {"group_0": {"targets": ["Linear"], "weights": w_args,
+                                      "input_activations": None if strategy == "block" else act}}})
+    cfg.packed_modules_mapping = _CT_FUSED
+    with torch.device(DEV):
+        gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16,
+                                        quant_config=cfg, prefix="model.layers.0.mlp.gate_up_proj", return_bias=False)
+    ws, ss = [], []
+    for i in range(2):
+        w8 = orc.f32_to_e4m3((rng.standard_normal((inter, hidden)) * 30).astype(np.float32))
+        gu.weight_loader(gu.weight, torch.from_numpy(w8).view(torch.float8_e4m3fn), i)
+        if strategy == "tensor":
+            s = np.float32(0.002 * (i + 1))
+            gu.weight_loader(gu.weight_scale, torch.tensor(s), i)
+            ss.append(np.full(inter, s, dtype=np.float32))
+        elif strategy == "channel":
+            s = (0.001 + 0.002 * rng.random((inter, 1))).astype(np.float32)
+            gu.weight_loader(gu.weight_scale, torch.from_numpy(s), i)
+            ss.append(s.reshape(-1))
+        else:
+            s = (0.001 + 0.002 * rng.random((inter // 128, hidden // 128))).astype(np.float32)
+            gu.weight_loader(gu.weight_scale, torch.from_numpy(s), i)
+            ss.append(s)
+        ws.append(w8)
+    gu.process_weights_after_loading()
+    x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    ref = orc.w8a16_gemm(x, np.concatenate(ws), np.concatenate(ss), None,
+                         block=(128, 128) if strategy == "block" else None)
+    got = gu(to_dev(x))
+    np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=1e-2)
+    assert (to_bits(got) == ref).mean() > 0.97

@@ -220,8 +220,9 @@ class MI355XW8A16LinearKernel(MPLinearKernel):
     """8-bit symmetric integer weights (GPTQ 8 bits, uint8b128) x 16-bit activations on gfx950.
 
     After process_weights_after_loading the layer holds <w_q> as uint8 [N, K] (values biased by 128)
-    and <w_s> as fp32 [N, K/G].  Checkpoint layout: weight int32 [K/4, N] packed along K, scales
-    [K/G, N].  Activation reordering is not served (8-bit checkpoints with desc_act are refused)."""
+    and <w_s> as fp32 [N, K/G].  Checkpoint layouts: weight int32 [K/4, N] packed along K with scales
+    [K/G, N] (GPTQ), or weight int32 [N, K/4] with scales [N, K/G] (compressed-tensors).  Activation
+    reordering is not served (8-bit checkpoints with desc_act are refused)."""
 
     @classmethod
     def get_min_capability(cls) -> int:
@@ -248,9 +249,17 @@ class MI355XW8A16LinearKernel(MPLinearKernel):
         K, N = c.partition_weight_shape
         G = K if c.group_size == -1 else c.group_size
         w_q, w_s, _, _ = self._get_weight_params(layer)
-        if tuple(w_q.shape) != (K // 4, N):
-            raise ValueError(f"{self.w_q_name}: shape {tuple(w_q.shape)} != ({K // 4}, {N})")
-        w, s = ops.gptq8_repack(w_q.data, w_s.data, G)
+        k_major = tuple(w_q.shape) == (K // 4, N) and (K // 4 != N or getattr(w_q, "output_dim", 1) != 0)
+        if k_major:                                   # GPTQ: int32 [K/4, N], scales [K/G, N]
+            w, s = ops.gptq8_repack(w_q.data, w_s.data, G)
+        elif tuple(w_q.shape) == (N, K // 4):         # compressed-tensors: int32 [N, K/4], scales [N, K/G]
+            if tuple(w_s.shape) != (N, K // G):
+                raise ValueError(f"{self.w_s_name}: shape {tuple(w_s.shape)} != ({N}, {K // G})")
+            # four consecutive k per word, least significant byte first: the bytes already are [N, K]
+            w = w_q.data.contiguous().view(torch.uint8).reshape(N, K)
+            s = w_s.data.to(torch.float32).contiguous()
+        else:
+            raise ValueError(f"{self.w_q_name}: shape {tuple(w_q.shape)} is neither ({K // 4}, {N}) nor ({N}, {K // 4})")
         _set_param(layer, self.w_q_name, w)
         _set_param(layer, self.w_s_name, s)
         if self.w_zp_name is not None:
