@@ -108,6 +108,61 @@ __global__ __launch_bounds__(NT) void fused_add_rms_norm_kernel(
   }
 }
 
+// Rows that fit in registers (H <= 8 NT VPT elements, 16-byte aligned): x, residual and the norm
+// weight are all requested before anything is consumed, so the row costs one memory round trip,
+// one reduction and one write.  Same per-element arithmetic as the kernel above.
+template <typename DT, int NT, int VPT>
+__global__ __launch_bounds__(NT) void fused_add_rms_norm_vec_kernel(
+    uint16_t* __restrict__ xio, int64_t x_stride, uint16_t* __restrict__ residual,
+    const uint16_t* __restrict__ w, float eps, int H) {
+  __shared__ float scratch[NT / 64];
+  u32x4* x = reinterpret_cast<u32x4*>(xio + (size_t)blockIdx.x * x_stride);
+  u32x4* r = reinterpret_cast<u32x4*>(residual + (size_t)blockIdx.x * H);
+  const u32x4* wv = reinterpret_cast<const u32x4*>(w);
+  const int nv = H >> 3;
+  u32x4 xv[VPT], rv[VPT], ww[VPT];
+#pragma unroll
+  for (int j = 0; j < VPT; j++) {
+    const int i = min((int)threadIdx.x + j * NT, nv - 1);   // clamped: the loads stay unconditional
+    xv[j] = x[i];
+    rv[j] = r[i];
+    ww[j] = w ? wv[i] : u32x4{0, 0, 0, 0};
+  }
+  float z[VPT][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPT; j++) {
+    const bool live = (int)threadIdx.x + j * NT < nv;
+    u32x4 zo;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint16_t z0 = DT::from_f32(DT::to_f32((uint16_t)(xv[j][e] & 0xffff)) + DT::to_f32((uint16_t)(rv[j][e] & 0xffff)));
+      const uint16_t z1 = DT::from_f32(DT::to_f32((uint16_t)(xv[j][e] >> 16)) + DT::to_f32((uint16_t)(rv[j][e] >> 16)));
+      zo[e] = (uint32_t)z0 | ((uint32_t)z1 << 16);
+      z[j][2 * e] = DT::to_f32(z0);
+      z[j][2 * e + 1] = DT::to_f32(z1);
+      if (live) ss += z[j][2 * e] * z[j][2 * e] + z[j][2 * e + 1] * z[j][2 * e + 1];
+    }
+    if (live) r[threadIdx.x + j * NT] = zo;
+  }
+  const float rs = rsqrtf(block_sum<NT / 64>(ss, scratch) / (float)H + eps);
+#pragma unroll
+  for (int j = 0; j < VPT; j++) {
+    if ((int)threadIdx.x + j * NT >= nv) continue;
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float a = z[j][2 * e] * rs, b = z[j][2 * e + 1] * rs;
+      if (w) {
+        a *= DT::to_f32((uint16_t)(ww[j][e] & 0xffff));
+        b *= DT::to_f32((uint16_t)(ww[j][e] >> 16));
+      }
+      o[e] = (uint32_t)DT::from_f32(a) | ((uint32_t)DT::from_f32(b) << 16);
+    }
+    x[threadIdx.x + j * NT] = o;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // RoPE (in place)
 // ---------------------------------------------------------------------------
@@ -398,6 +453,19 @@ extern "C" int mi355q_fused_add_rms_norm(void* input, int64_t input_stride, void
   if (num_tokens == 0) return MI355Q_OK;
   MI355Q_REQUIRE(input && residual && hidden > 0 && num_tokens >= 0, "fused_add_rms_norm: bad arguments");
   hipStream_t s = (hipStream_t)stream;
+  const bool aligned = hidden % 8 == 0 && input_stride % 8 == 0 && (((uintptr_t)input | (uintptr_t)residual | (uintptr_t)weight) & 15) == 0;
+  if (aligned && hidden <= 8 * 256 * 4 && !getenv("MI355Q_NORM_SCALAR")) {
+    if (hidden <= 8 * 256 * 2) {
+      DISPATCH_H16(dtype, hipLaunchKernelGGL((fused_add_rms_norm_vec_kernel<DT, 256, 2>), dim3(num_tokens), dim3(256), 0, s,
+                                             (uint16_t*)input, input_stride, (uint16_t*)residual,
+                                             (const uint16_t*)weight, epsilon, hidden));
+    } else {
+      DISPATCH_H16(dtype, hipLaunchKernelGGL((fused_add_rms_norm_vec_kernel<DT, 256, 4>), dim3(num_tokens), dim3(256), 0, s,
+                                             (uint16_t*)input, input_stride, (uint16_t*)residual,
+                                             (const uint16_t*)weight, epsilon, hidden));
+    }
+    return check_launch("fused_add_rms_norm_vec_kernel");
+  }
   DISPATCH_H16(dtype, hipLaunchKernelGGL((fused_add_rms_norm_kernel<DT, 1024, false>), dim3(num_tokens),
                                          dim3(1024), 0, s, (uint16_t*)input, input_stride,
                                          (uint16_t*)residual, (const float*)nullptr, 0, (size_t)0,
