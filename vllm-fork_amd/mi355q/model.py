@@ -30,8 +30,10 @@ class LlamaConfig:
     max_pos: int = 8192
 
 
-# token counts up to which add+RMSNorm runs in the prologue of the GEMM that consumes it
-FUSE_NORM_MAX_TOKENS = int(os.environ.get("MI355Q_FUSE_NORM_MAX", "4"))
+# token counts up to which add+RMSNorm runs in the prologue of the GEMM that consumes it: every
+# workgroup of that GEMM repeats the norm, which beats the separate launch for one row (1.71 vs
+# 1.79 ms per step) and loses from two rows on (batch 4: 2.15 vs 2.03 ms)
+FUSE_NORM_MAX_TOKENS = int(os.environ.get("MI355Q_FUSE_NORM_MAX", "1"))
 
 CONFIGS = {
     "llama3-8b": LlamaConfig("llama3-8b", 4096, 14336, 32, 32, 8, 128, 128256),
@@ -314,9 +316,10 @@ class LlamaRunner:
         """One decode step for the whole static batch: consumes self.tokens/positions/seq_lens,
         leaves the sampled ids in self.tokens and advances the positions."""
         B = self.max_batch
-        slot_mapping = self.slot_base + self.positions
-        attend = None
+        attend = slot_mapping = None   # the fused attention step derives the slot from the block table
         if self.fp8 and self.cfg.head_dim != 128:  # the fused step needs head 128 with an fp8 cache
+            slot_mapping = self.slot_base + self.positions
+
             def attend(li, q, out):
                 ops.paged_attention_rocm(out, self.exp_sums, self.max_logits, self.tmp_out, q, self.kc[li], self.vc[li],
                                          self.kv_heads, self.scale, self.block_tables, self.seq_lens, None,
@@ -327,8 +330,7 @@ class LlamaRunner:
         residual = None
         for li, L in enumerate(self.layers):
             h, residual = self._layer(L, li, h, residual, self.positions, slot_mapping, attend)
-        ids = ops.argmax(self._logits(h, residual))
-        self.tokens.copy_(ids)
+        ops.argmax(self._logits(h, residual), out=self.tokens)
         self.positions.add_(1)
         self.seq_lens.add_(1)
 

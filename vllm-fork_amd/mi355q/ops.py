@@ -662,12 +662,17 @@ def decode_attention_fused(out, exp_sum, max_logits, tmp_out, qkv, positions, co
 # ---------------------------------------------------------------------------
 # sampler inner loop
 # ---------------------------------------------------------------------------
-def argmax(logits: torch.Tensor) -> torch.Tensor:
-    """logits.float().argmax(-1) with first-index ties (vllm/v1/sample/sampler.py:96,240-241)."""
+def argmax(logits: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """logits.float().argmax(-1) with first-index ties (vllm/v1/sample/sampler.py:96,240-241).
+    `out` (int64 [rows], contiguous) receives the ids when given."""
     _need_cuda(logits)
     if logits.dim() != 2 or logits.stride(1) != 1:
         raise RuntimeError("argmax: logits must be [rows, vocab] with a contiguous last dim")
-    ids = torch.empty((logits.shape[0],), dtype=torch.int64, device=logits.device)
+    if out is not None:
+        _need_cuda(out)
+        if out.dtype != torch.int64 or out.shape != (logits.shape[0],) or not out.is_contiguous():
+            raise RuntimeError("argmax: out must be a contiguous int64 tensor with one entry per row")
+    ids = out if out is not None else torch.empty((logits.shape[0],), dtype=torch.int64, device=logits.device)
     check(_lib.lib().mi355q_argmax(logits.data_ptr(), logits.stride(0), ids.data_ptr(), logits.shape[0],
                                    logits.shape[1], _dt(logits, True), _stream()))
     return ids
