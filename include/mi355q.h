@@ -347,6 +347,19 @@ int mi355q_reshape_and_cache(const void* key, const void* value, int64_t key_str
                              int head_size, int block_size, int64_t block_stride, int dtype,
                              int kv_fp8, const float* k_scale, const float* v_scale,
                              mi355q_stream_t stream);
+/* mi355q_rotary_embedding followed by mi355q_reshape_and_cache in one launch: q and k are rotated in
+ * place, the rotated k and v are written to the paged cache (same layouts, same fp8 conversion; a
+ * negative slot rotates the token without caching it).  Replaces the backend hook
+ * do_rope_and_kv_cache_update (vllm/v1/attention/backends/rocm_attn.py:522-562, which calls AITER's
+ * triton_rope_and_cache) and the op fused_rope_and_unified_kv_cache_update
+ * (vllm/compilation/passes/fusion/rope_kvcache_fusion.py:46-96). */
+int mi355q_rope_and_cache(const int64_t* positions, void* query, int64_t query_stride, void* key,
+                          int64_t key_stride, const void* value, int64_t value_stride, int head_size,
+                          int num_heads, int num_kv_heads, const void* cos_sin_cache, int rot_dim,
+                          int cache_dtype, int is_neox, void* key_cache, void* value_cache,
+                          const int64_t* slot_mapping, int num_tokens, int block_size,
+                          int64_t block_stride, int dtype, int kv_fp8, const float* k_scale,
+                          const float* v_scale, mi355q_stream_t stream);
 /* dst = fp8 -> dtype or dtype -> fp8 element-wise with scale.  Replaces
  * ops.convert_fp8 (vllm/_custom_ops.py:2908; cache_kernels.cu:1003-1060). */
 int mi355q_convert_fp8(void* dst, const void* src, int64_t n, float scale, int dtype,

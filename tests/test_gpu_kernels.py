@@ -425,6 +425,46 @@ def test_reshape_and_cache(fp8, bs, head):
         assert np.array_equal(to_bits(back), expect)
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("head,rot,neox,bs", [(128, 128, True, 16), (64, 64, False, 32), (128, 32, True, 16)])
+def test_rope_and_cache_matches_the_oracle_sequence(fp8, head, rot, neox, bs):
+    """One launch = rotary_embedding, then reshape_and_cache on the rotated key: checked bit for bit
+    against the oracle's two steps (NeoX and GPT-J pairing, partial rotary, fp8 cache, a skipped slot)."""
+    rng = np.random.default_rng(31)
+    T, nh, kvh, nblk, max_pos = 11, 4, 2, 6, 64
+    x = 16 if fp8 else 8
+    q = orc.f32_to_h16(rng.standard_normal((T, nh * head)).astype(np.float32))
+    k = orc.f32_to_h16(rng.standard_normal((T, kvh * head)).astype(np.float32))
+    v = orc.f32_to_h16(rng.standard_normal((T, kvh * head)).astype(np.float32))
+    pos = rng.integers(0, max_pos, size=T).astype(np.int64)
+    inv = 1.0 / (10000.0 ** (np.arange(0, rot, 2, dtype=np.float32) / rot))
+    fr = np.arange(max_pos, dtype=np.float32)[:, None] * inv[None, :]
+    cache = orc.f32_to_h16(np.concatenate([np.cos(fr), np.sin(fr)], axis=1).astype(np.float32))
+    slots = rng.permutation(nblk * bs)[:T].astype(np.int64)
+    slots[4] = -1
+    ks, vs = (0.05, 0.02) if fp8 else (1.0, 1.0)
+    qo, ko = orc.rotary_embedding(pos, q, k, cache, head, int(neox))
+    cdt = np.uint8 if fp8 else np.uint16
+    kc_ref = np.zeros((nblk, kvh, head // x, bs, x), dtype=cdt)
+    vc_ref = np.zeros((nblk, kvh, head, bs), dtype=cdt)
+    orc.reshape_and_cache(ko.reshape(T, kvh, head), v.reshape(T, kvh, head), kc_ref, vc_ref, slots, fp8=fp8,
+                          k_scale=ks, v_scale=vs)
+    tdt = torch.uint8 if fp8 else torch.bfloat16
+    kc = torch.zeros((nblk, kvh, head // x, bs, x), dtype=tdt, device=DEV)
+    vc = torch.zeros((nblk, kvh, head, bs), dtype=tdt, device=DEV)
+    # q, k, v as slices of one fused projection output, as the model passes them
+    qkv = to_dev(np.concatenate([q, k, v], axis=1))
+    qs, ksz = nh * head, kvh * head
+    qd, kd, vd = qkv[:, :qs], qkv[:, qs:qs + ksz], qkv[:, qs + ksz:]
+    ops.rope_and_cache(torch.from_numpy(pos).to(DEV), qd, kd, vd, head, to_dev(cache), neox, kc, vc,
+                       torch.from_numpy(slots).to(DEV), "fp8" if fp8 else "auto",
+                       torch.tensor(ks, dtype=torch.float32, device=DEV), torch.tensor(vs, dtype=torch.float32, device=DEV))
+    assert np.array_equal(to_bits(qd), qo) and np.array_equal(to_bits(kd), ko)
+    assert np.array_equal(to_bits(vd), v)
+    assert np.array_equal(kc.cpu().numpy() if fp8 else to_bits(kc), kc_ref)
+    assert np.array_equal(vc.cpu().numpy() if fp8 else to_bits(vc), vc_ref)
+
+
 def _run_paged(g, tag, varlen_rows=None):
     H, KVH, D, bs, fp8 = [int(v) for v in g[tag + "_meta"]]
     scale = float(g[tag + "_scale"][0])

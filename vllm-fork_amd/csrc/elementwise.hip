@@ -241,6 +241,63 @@ __global__ void reshape_and_cache_kernel(const uint16_t* __restrict__ key,
   }
 }
 
+// RoPE on q and k (in place) and the KV-cache write of the rotated k and of v in one pass over the
+// token: what rotary_kernel followed by reshape_and_cache_kernel leave behind, bit for bit (the cache
+// receives k as rounded to the activation dtype by the rotation).  Tokens whose slot is negative are
+// rotated and not cached.
+template <typename DT, bool FP8>
+__global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uint16_t* __restrict__ q,
+                                      int64_t q_stride, uint16_t* __restrict__ k, int64_t k_stride,
+                                      const uint16_t* __restrict__ v, int64_t v_stride, int head, int nh,
+                                      int nkv, const void* __restrict__ cache, int rot, int cache_dtype,
+                                      int is_neox, void* __restrict__ kc, void* __restrict__ vc,
+                                      const int64_t* __restrict__ slot_mapping, int bs, int64_t block_stride,
+                                      const float* __restrict__ k_scale, const float* __restrict__ v_scale) {
+  const int t = blockIdx.x;
+  const int e = rot / 2;
+  const size_t cbase = (size_t)positions[t] * rot;
+  const int64_t slot = slot_mapping[t];
+  const int64_t b = slot / bs, o = slot % bs;
+  constexpr int X = FP8 ? 16 : 8;
+  const float ks = FP8 ? *k_scale : 1.f, vs = FP8 ? *v_scale : 1.f;
+  auto put_k = [&](int h, int d, uint16_t bits) {
+    const size_t ki = (size_t)b * block_stride + (((size_t)h * (head / X) + d / X) * bs + o) * X + d % X;
+    if constexpr (FP8) reinterpret_cast<uint8_t*>(kc)[ki] = f32_to_fp8(DT::to_f32(bits) / ks);
+    else reinterpret_cast<uint16_t*>(kc)[ki] = bits;
+  };
+  const int total = (nh + nkv) * e;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int h = idx / e, i = idx - h * e;
+    const bool is_k = h >= nh;
+    uint16_t* arr = is_k ? k + (size_t)t * k_stride + (size_t)(h - nh) * head : q + (size_t)t * q_stride + (size_t)h * head;
+    const int xi = is_neox ? i : 2 * i, yi = is_neox ? e + i : 2 * i + 1;
+    const float c = load_cache(cache, cbase + i, cache_dtype);
+    const float s = load_cache(cache, cbase + e + i, cache_dtype);
+    const float xf = DT::to_f32(arr[xi]), yf = DT::to_f32(arr[yi]);
+    const uint16_t xo = DT::from_f32(xf * c - yf * s), yo = DT::from_f32(yf * c + xf * s);
+    arr[xi] = xo;
+    arr[yi] = yo;
+    if (is_k && slot >= 0) {
+      put_k(h - nh, xi, xo);
+      put_k(h - nh, yi, yo);
+    }
+  }
+  if (slot < 0) return;
+  // the part of k beyond the rotated dimensions (partial rotary), then v
+  const int tail = head - rot;
+  for (int idx = threadIdx.x; idx < nkv * tail; idx += blockDim.x) {
+    const int h = idx / tail, d = rot + idx - h * tail;
+    put_k(h, d, k[(size_t)t * k_stride + (size_t)h * head + d]);
+  }
+  for (int idx = threadIdx.x; idx < nkv * head; idx += blockDim.x) {
+    const int h = idx / head, d = idx - h * head;
+    const uint16_t vb = v[(size_t)t * v_stride + idx];
+    const size_t vi = (size_t)b * block_stride + ((size_t)h * head + d) * bs + o;
+    if constexpr (FP8) reinterpret_cast<uint8_t*>(vc)[vi] = f32_to_fp8(DT::to_f32(vb) / vs);
+    else reinterpret_cast<uint16_t*>(vc)[vi] = vb;
+  }
+}
+
 template <typename DT>
 __global__ void convert_fp8_kernel(void* __restrict__ dst, const void* __restrict__ src, int64_t n,
                                    float scale, int to_fp8) {
@@ -548,6 +605,37 @@ extern "C" int mi355q_reshape_and_cache(const void* key, const void* value, int6
                                            block_size, block_stride, k_scale, v_scale));
   }
   return check_launch("reshape_and_cache_kernel");
+}
+
+extern "C" int mi355q_rope_and_cache(const int64_t* positions, void* query, int64_t query_stride, void* key,
+                                     int64_t key_stride, const void* value, int64_t value_stride,
+                                     int head_size, int num_heads, int num_kv_heads,
+                                     const void* cos_sin_cache, int rot_dim, int cache_dtype, int is_neox,
+                                     void* key_cache, void* value_cache, const int64_t* slot_mapping,
+                                     int num_tokens, int block_size, int64_t block_stride, int dtype,
+                                     int kv_fp8, const float* k_scale, const float* v_scale,
+                                     mi355q_stream_t stream) {
+  if (int e = check_h16(dtype, "rope_and_cache")) return e;
+  if (num_tokens == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(positions && query && key && value && cos_sin_cache && key_cache && value_cache && slot_mapping,
+                 "rope_and_cache: null pointer");
+  MI355Q_REQUIRE(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "rope_and_cache: rot_dim %d vs head_size %d", rot_dim, head_size);
+  MI355Q_REQUIRE(cache_dtype >= MI355Q_BF16 && cache_dtype <= MI355Q_FP32, "rope_and_cache: bad cache dtype");
+  MI355Q_REQUIRE(head_size % (kv_fp8 ? 16 : 8) == 0, "rope_and_cache: head_size %d", head_size);
+  MI355Q_REQUIRE(num_heads > 0 && num_kv_heads > 0 && block_size > 0, "rope_and_cache: bad sizes");
+  if (kv_fp8) MI355Q_REQUIRE(k_scale && v_scale, "rope_and_cache: fp8 cache needs k_scale/v_scale");
+  int threads = (num_heads + num_kv_heads) * rot_dim / 2;
+  threads = threads < 64 ? 64 : (threads > 1024 ? 1024 : (threads + 63) / 64 * 64);
+  hipStream_t s = (hipStream_t)stream;
+#define MI355Q_RC(F8)                                                                                            \
+  DISPATCH_H16(dtype, hipLaunchKernelGGL((rope_and_cache_kernel<DT, F8>), dim3(num_tokens), dim3(threads), 0, s,   \
+                                         positions, (uint16_t*)query, query_stride, (uint16_t*)key, key_stride,     \
+                                         (const uint16_t*)value, value_stride, head_size, num_heads, num_kv_heads, \
+                                         cos_sin_cache, rot_dim, cache_dtype, is_neox, key_cache, value_cache,      \
+                                         slot_mapping, block_size, block_stride, k_scale, v_scale))
+  if (kv_fp8) { MI355Q_RC(true); } else { MI355Q_RC(false); }
+#undef MI355Q_RC
+  return check_launch("rope_and_cache_kernel");
 }
 
 extern "C" int mi355q_convert_fp8(void* dst, const void* src, int64_t n, float scale, int dtype,

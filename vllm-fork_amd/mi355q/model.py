@@ -239,9 +239,8 @@ class LlamaRunner:
                                        self.max_seq_len, self.kv_cache_dtype, self.k_scale, self.v_scale)
         else:
             q, k, v = qkv[:, :qs], qkv[:, qs:qs + ks], qkv[:, qs + ks:]
-            ops.rotary_embedding(positions, q, k, D, self.cos_sin, True)
-            ops.reshape_and_cache(k.view(T, self.kv_heads, D), v.view(T, self.kv_heads, D), self.kc[li], self.vc[li],
-                                  slot_mapping, self.kv_cache_dtype, self.k_scale, self.v_scale)
+            ops.rope_and_cache(positions, q, k, v, D, self.cos_sin, True, self.kc[li], self.vc[li], slot_mapping,
+                               self.kv_cache_dtype, self.k_scale, self.v_scale)
             attend(li, q.view(T, self.heads, D), attn)
         o = self._all_reduce(L["o"](attn.view(T, qs)))
         if self.quant != "none" and L["gate_up"].w.pair_halves:

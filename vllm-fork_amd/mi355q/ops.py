@@ -595,6 +595,32 @@ def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, kv_cache
         _dt(key), int(_is_fp8(kv_cache_dtype)), _ptr(k_scale), _ptr(v_scale), _stream()))
 
 
+def rope_and_cache(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                   head_size: int, cos_sin_cache: torch.Tensor, is_neox: bool, key_cache: torch.Tensor,
+                   value_cache: torch.Tensor, slot_mapping: torch.Tensor, kv_cache_dtype: str, k_scale, v_scale) -> None:
+    """rotary_embedding + reshape_and_cache in one launch (the arguments of
+    rocm_aiter_ops.triton_rope_and_cache as called at vllm/v1/attention/backends/rocm_attn.py:548-562):
+    query / key [T, heads * head] are rotated in place, the rotated key and value [T, kv_heads * head]
+    go to the paged cache."""
+    _need_cuda(positions, query, key, value, cos_sin_cache, key_cache, value_cache, slot_mapping)
+    T = positions.numel()
+    if positions.dtype != torch.int64 or slot_mapping.dtype != torch.int64:
+        raise RuntimeError("rope_and_cache: positions and slot_mapping must be int64")
+    if slot_mapping.numel() != T:
+        raise RuntimeError(f"rope_and_cache: {slot_mapping.numel()} slots for {T} positions")
+    q2, k2, v2 = query.view(T, -1), key.view(T, -1), value.view(T, -1)
+    if q2.stride(1) != 1 or k2.stride(1) != 1 or v2.stride(1) != 1:
+        raise RuntimeError("rope_and_cache: query / key / value rows must be contiguous")
+    nh, nkv = q2.shape[1] // head_size, k2.shape[1] // head_size
+    if v2.shape[1] != nkv * head_size or key_cache.shape[1] != nkv or value_cache.shape[1] != nkv:
+        raise RuntimeError("rope_and_cache: key / value / cache head counts differ")
+    check(_lib.lib().mi355q_rope_and_cache(
+        positions.data_ptr(), q2.data_ptr(), q2.stride(0), k2.data_ptr(), k2.stride(0), v2.data_ptr(), v2.stride(0),
+        head_size, nh, nkv, cos_sin_cache.data_ptr(), cos_sin_cache.shape[1], _dt(cos_sin_cache, True), int(is_neox),
+        key_cache.data_ptr(), value_cache.data_ptr(), slot_mapping.data_ptr(), T, value_cache.shape[3],
+        key_cache.stride(0), _dt(query), int(_is_fp8(kv_cache_dtype)), _ptr(k_scale), _ptr(v_scale), _stream()))
+
+
 def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0, kv_dtype: str = "fp8") -> None:
     """ops.convert_fp8 (vllm/_custom_ops.py:2908): fp8 cache <-> 16-bit tensor."""
     _need_cuda(output, input)

@@ -189,6 +189,18 @@ class Mi355AttentionImpl:
         return output
 
     def fused_rope_kvcache_supported(self) -> bool:
+        return True
+
+    def do_rope_and_kv_cache_update(self, layer, query, key, value, positions, cos_sin_cache, is_neox, kv_cache,
+                                    layer_slot_mapping) -> None:
+        """RoPE on query / key and the cache write of the rotated key and of value in one launch
+        (rocm_attn.py:522-562)."""
+        k, v = self._caches(kv_cache)
+        T = layer_slot_mapping.numel()
+        ops.rope_and_cache(positions[:T], query[:T], key[:T], value[:T], self.head_size, cos_sin_cache, is_neox, k, v,
+                           layer_slot_mapping, self.kv_cache_dtype, layer._k_scale, layer._v_scale)
+
+    def decode_fused_supported(self) -> bool:
         return self.head_size == 128 or not is_quantized_kv_cache(self.kv_cache_dtype)
 
     def forward_decode_fused(self, layer, qkv, positions, cos_sin_cache, kv_cache,
