@@ -189,6 +189,16 @@ int mi355q_w4a16_mm_supported(int N, int K, int G, int tile);
 int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const void* scales, const void* zc,
                     const void* bias, void* c, int M, int N, int K, int G, int tile, int act_dtype,
                     int silu_pairs, void* workspace, size_t workspace_bytes, mi355q_stream_t stream);
+/* mi355q_w4a16_mm followed by mi355q_fused_add_rms_norm on its result (row-parallel projection ->
+ * residual add -> RMSNorm, vllm/model_executor/models/llama.py:311-328): residual = round(c + residual),
+ * out = RMSNorm(residual) * norm_weight.  When the GEMM is cut into K-slices, the slice sums, the
+ * bias, the residual add and the norm run as one kernel over the fp32 partial tiles.  Same
+ * workspace as mi355q_w4a16_mm. */
+int mi355q_w4a16_mm_add_rms_norm(const void* a, int lda, const void* packed, const void* scales,
+                                 const void* zc, const void* bias, void* residual,
+                                 const void* norm_weight, float epsilon, void* out, int M, int N,
+                                 int K, int G, int tile, int act_dtype, void* workspace,
+                                 size_t workspace_bytes, mi355q_stream_t stream);
 
 /*
  * gate_up projection with SiluAndMul in its epilogue, for weights repacked with

@@ -174,6 +174,38 @@ def test_w4a16_mm_vs_oracle(M, K, N, G, tile, awq, dt):
     assert torch.equal(out, ops.w4a16_mm(to_dev(a, dt), w, bias=to_dev(bias, dt)))
 
 
+@pytest.mark.parametrize("M,K,N,with_bias", [(128, 4096, 4096, False), (32, 14336, 4096, True), (600, 1024, 4096, False),
+                                              (20, 512, 8192, True)])
+def test_w4a16_mm_add_rms_norm_equals_the_two_steps(M, K, N, with_bias):
+    """Projection + residual add + RMSNorm as one call: the residual is bit-identical to
+    w4a16_mm followed by fused_add_rms_norm (same slice-order sums, same roundings); the normalised rows
+    may differ by one rounding where the sum of squares was added in another order.  Also against the
+    oracle's GEMM + fused_add_rms_norm."""
+    rng = np.random.default_rng(M + K + N)
+    G = 128
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    a = orc.f32_to_h16(0.25 * rng.standard_normal((M, K)).astype(np.float32))
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N))).astype(np.float32))
+    res = orc.f32_to_h16(rng.standard_normal((M, N)).astype(np.float32))
+    nw = orc.f32_to_h16((1 + 0.1 * rng.standard_normal(N)).astype(np.float32))
+    bias = orc.f32_to_h16(rng.standard_normal(N).astype(np.float32)) if with_bias else None
+    qw = orc.gptq_pack(q)
+    w = ops.w4a16_repack(i32(qw), to_dev(s), None, G)
+    bias_d = None if bias is None else to_dev(bias)
+    c = ops.w4a16_mm(to_dev(a), w, bias=bias_d)
+    r2 = to_dev(res).clone()
+    ops.fused_add_rms_norm(c, r2, to_dev(nw), 1e-5)
+    r1 = to_dev(res).clone()
+    out = ops.w4a16_mm_add_rms_norm(to_dev(a), w, r1, to_dev(nw), 1e-5, bias=bias_d)
+    assert torch.equal(r1, r2)
+    assert (to_bits(out) == to_bits(c)).mean() > 0.999
+    np.testing.assert_allclose(f32(to_bits(out)), f32(to_bits(c)), rtol=2.0 ** -7, atol=1e-6)
+    ref_c = orc.w4a16_gemm(a, qw, s, None, bias, G=G)
+    ref_x, ref_r = orc.fused_add_rms_norm(ref_c, res, nw, 1e-5)
+    assert (to_bits(r1) == ref_r).mean() > 0.97
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref_x), rtol=2e-2, atol=2e-2)
+
+
 def test_w4a16_mm_silu_pairs_and_routing(monkeypatch):
     """pair_halves weight + SiLU epilogue = silu_and_mul of the plain projection; w4a16_gemm routes
     17..1024 tokens to the tiled kernel and refuses nothing it used to serve."""

@@ -163,6 +163,83 @@ __global__ __launch_bounds__(NT) void fused_add_rms_norm_vec_kernel(
   }
 }
 
+// The same from fp32 K-slice partials: c = round(sum_s partial[s]) (+ bias, rounded again) stands in
+// for x, the normalised row goes to `out`.  Four channels per vector, VPT vectors per thread held in
+// registers (H <= 4 NT VPT); sixteen waves per row keep enough requests in flight for the slices.
+template <typename DT, int NT, int VPT>
+__global__ __launch_bounds__(NT) void splitk_add_rms_norm_vec_kernel(
+    uint16_t* __restrict__ out, uint16_t* __restrict__ residual, const float* __restrict__ partial, int splits,
+    size_t split_stride, const uint16_t* __restrict__ bias, const uint16_t* __restrict__ w, float eps, int H) {
+  __shared__ float scratch[NT / 64];
+  const int nv = H >> 2;
+  u32x2* o = reinterpret_cast<u32x2*>(out + (size_t)blockIdx.x * H);
+  u32x2* r = reinterpret_cast<u32x2*>(residual + (size_t)blockIdx.x * H);
+  const f32x4* pp = reinterpret_cast<const f32x4*>(partial + (size_t)blockIdx.x * H);
+  const size_t sstr = split_stride >> 2;
+  auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
+  auto hi = [](uint32_t u) { return DT::to_f32((uint16_t)(u >> 16)); };
+  int idx[VPT];
+  u32x2 rv[VPT], wv[VPT], bv[VPT];
+  f32x4 acc[VPT];
+#pragma unroll
+  for (int j = 0; j < VPT; j++) {
+    idx[j] = min((int)threadIdx.x + j * NT, nv - 1);   // clamped: the loads stay unconditional
+    rv[j] = r[idx[j]];
+    wv[j] = w ? reinterpret_cast<const u32x2*>(w)[idx[j]] : u32x2{0u, 0u};
+    bv[j] = bias ? reinterpret_cast<const u32x2*>(bias)[idx[j]] : u32x2{0u, 0u};
+    acc[j] = pp[idx[j]];
+  }
+  // eight slices requested at a time (clamped, so the requests are unconditional), added in slice order
+  for (int sp0 = 1; sp0 < splits; sp0 += 8) {
+    f32x4 t[8][VPT];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const size_t base = (size_t)min(sp0 + u, splits - 1) * sstr;
+#pragma unroll
+      for (int j = 0; j < VPT; j++) t[u][j] = pp[base + idx[j]];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (sp0 + u < splits) {
+#pragma unroll
+        for (int j = 0; j < VPT; j++) acc[j] += t[u][j];
+      }
+    }
+  }
+  float z[VPT][4];
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPT; j++) {
+    const bool live = (int)threadIdx.x + j * NT < nv;
+    const float rr[4] = {lo(rv[j][0]), hi(rv[j][0]), lo(rv[j][1]), hi(rv[j][1])};
+    const float bb[4] = {lo(bv[j][0]), hi(bv[j][0]), lo(bv[j][1]), hi(bv[j][1])};
+    uint16_t zb[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float c = DT::to_f32(DT::from_f32(acc[j][e]));
+      if (bias) c = DT::to_f32(DT::from_f32(c + bb[e]));
+      zb[e] = DT::from_f32(c + rr[e]);
+      z[j][e] = DT::to_f32(zb[e]);
+      if (live) ss += z[j][e] * z[j][e];
+    }
+    if (live) r[threadIdx.x + j * NT] = u32x2{(uint32_t)zb[0] | ((uint32_t)zb[1] << 16), (uint32_t)zb[2] | ((uint32_t)zb[3] << 16)};
+  }
+  const float rs = rsqrtf(block_sum<NT / 64>(ss, scratch) / (float)H + eps);
+#pragma unroll
+  for (int j = 0; j < VPT; j++) {
+    if ((int)threadIdx.x + j * NT >= nv) continue;
+    const float ww[4] = {lo(wv[j][0]), hi(wv[j][0]), lo(wv[j][1]), hi(wv[j][1])};
+    uint16_t ob[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float a = z[j][e] * rs;
+      if (w) a *= ww[e];
+      ob[e] = DT::from_f32(a);
+    }
+    o[threadIdx.x + j * NT] = u32x2{(uint32_t)ob[0] | ((uint32_t)ob[1] << 16), (uint32_t)ob[2] | ((uint32_t)ob[3] << 16)};
+  }
+}
+
 // ---------------------------------------------------------------------------
 // RoPE (in place)
 // ---------------------------------------------------------------------------
@@ -539,6 +616,21 @@ extern "C" int mi355q_splitk_add_rms_norm(void* out, void* residual, const float
   MI355Q_REQUIRE(out && residual && partial && splits >= 1 && hidden > 0 && num_tokens >= 0,
                  "splitk_add_rms_norm: bad arguments");
   hipStream_t s = (hipStream_t)stream;
+  const bool aligned = hidden % 4 == 0 && (((uintptr_t)out | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)bias) & 7) == 0 &&
+                       ((uintptr_t)partial & 15) == 0;
+  if (aligned && hidden <= 4 * 256 * 8 && !getenv("MI355Q_NORM_SCALAR")) {
+    const size_t sstr = (size_t)num_tokens * hidden;
+    if (hidden <= 4 * 1024) {
+      DISPATCH_H16(dtype, hipLaunchKernelGGL((splitk_add_rms_norm_vec_kernel<DT, 1024, 1>), dim3(num_tokens), dim3(1024), 0, s,
+                                             (uint16_t*)out, (uint16_t*)residual, partial, splits, sstr,
+                                             (const uint16_t*)bias, (const uint16_t*)weight, epsilon, hidden));
+    } else {
+      DISPATCH_H16(dtype, hipLaunchKernelGGL((splitk_add_rms_norm_vec_kernel<DT, 1024, 2>), dim3(num_tokens), dim3(1024), 0, s,
+                                             (uint16_t*)out, (uint16_t*)residual, partial, splits, sstr,
+                                             (const uint16_t*)bias, (const uint16_t*)weight, epsilon, hidden));
+    }
+    return check_launch("splitk_add_rms_norm_vec_kernel");
+  }
   DISPATCH_H16(dtype, hipLaunchKernelGGL((fused_add_rms_norm_kernel<DT, 1024, true>), dim3(num_tokens),
                                          dim3(1024), 0, s, (uint16_t*)out, (int64_t)hidden,
                                          (uint16_t*)residual, partial, splits,

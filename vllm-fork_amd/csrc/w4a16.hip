@@ -1709,7 +1709,7 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw) {
 }
 
 template <typename DT>
-static int launch_mm(const MmParams& p, const MmPlan& mp, hipStream_t stream) {
+static int launch_mm(const MmParams& p, const MmPlan& mp, hipStream_t stream, bool reduce = true) {
   const int bw = 4 * mp.spw * 16 * mp.ns;
   dim3 grid(p.N / bw, (p.M + 16 * MM_RT - 1) / (16 * MM_RT), p.splits), block(256);
 #define MI355Q_MM(NS_, SPW_)                                                                              \
@@ -1720,7 +1720,7 @@ static int launch_mm(const MmParams& p, const MmPlan& mp, hipStream_t stream) {
   MI355Q_MM(1, 4) else MI355Q_MM(2, 2) else MI355Q_MM(4, 1) else MI355Q_MM(7, 1)
 #undef MI355Q_MM
   if (int e = check_launch("w4a16_mm_kernel")) return e;
-  if (p.splits > 1) {
+  if (p.splits > 1 && reduce) {
     const size_t items = (size_t)p.M * (p.N >> 2);
     hipLaunchKernelGGL((w4a16_mm_reduce_kernel<DT>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p);
     return check_launch("w4a16_mm_reduce_kernel");
@@ -2093,4 +2093,44 @@ extern "C" int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const
     p.partial = (float*)workspace;
   }
   return act_dtype == MI355Q_BF16 ? launch_mm<BF16>(p, mp, (hipStream_t)stream) : launch_mm<FP16>(p, mp, (hipStream_t)stream);
+}
+
+/* c = a W (+ bias), then fused_add_rms_norm(c, residual): residual = round(c + residual),
+ * out = round(residual * rsqrt(mean(residual^2) + eps) * norm_weight).  With K-slices the slice sums,
+ * the residual add and the norm are one kernel over the fp32 partial tiles. */
+extern "C" int mi355q_w4a16_mm_add_rms_norm(const void* a, int lda, const void* packed, const void* scales,
+                                            const void* zc, const void* bias, void* residual,
+                                            const void* norm_weight, float epsilon, void* out, int M, int N,
+                                            int K, int G, int tile, int act_dtype, void* workspace,
+                                            size_t workspace_bytes, mi355q_stream_t stream) {
+  if (int e = check_shape(K, N, G)) return e;
+  if (int e = check_tile(tile, K, G, N)) return e;
+  MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w4a16_mm_add_rms_norm: act_dtype must be bf16 or fp16");
+  if (M == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(a && packed && scales && residual && out && M > 0, "w4a16_mm_add_rms_norm: bad arguments");
+  MI355Q_REQUIRE(lda % 8 == 0 && lda >= K, "w4a16_mm_add_rms_norm: row stride %d must be a multiple of 8 and cover the row", lda);
+  MI355Q_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)scales & 15) == 0 &&
+                     ((uintptr_t)out & 15) == 0 && ((uintptr_t)residual & 15) == 0 && ((uintptr_t)zc & 15) == 0 &&
+                     ((uintptr_t)bias & 7) == 0 && ((uintptr_t)norm_weight & 15) == 0,
+                 "w4a16_mm_add_rms_norm: pointers must be 16-byte aligned");
+  const MmPlan mp = plan_mm(M, N, K, G, tile);
+  MI355Q_REQUIRE(mp.ok, "w4a16_mm_add_rms_norm: needs a group size that is a multiple of 128 and N a multiple of %d for strip width %d",
+                 tile == 112 ? 448 : 256, tile);
+  MmParams p;
+  p.x = (const uint16_t*)a; p.ldx = lda; p.wp = (const u32x4*)packed;
+  p.scales = (const uint16_t*)scales; p.zc = (const uint16_t*)zc; p.bias = (const uint16_t*)bias;
+  p.out = (uint16_t*)out; p.partial = nullptr;
+  p.M = M; p.N = N; p.K = K; p.chunks = K / 128; p.gchunks = G / 128;
+  p.splits = mp.splits; p.cps = p.chunks / mp.splits; p.epi_silu = 0;
+  if (mp.splits > 1) {
+    MI355Q_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "w4a16_mm_add_rms_norm: K-slices need a 16-byte aligned workspace");
+    if (workspace_bytes < mp.ws) return set_error(MI355Q_ENOSPACE, "w4a16_mm_add_rms_norm: workspace %zu B < %zu B", workspace_bytes, mp.ws);
+    p.partial = (float*)workspace;
+  }
+  const int e = act_dtype == MI355Q_BF16 ? launch_mm<BF16>(p, mp, (hipStream_t)stream, false)
+                                         : launch_mm<FP16>(p, mp, (hipStream_t)stream, false);
+  if (e) return e;
+  if (mp.splits > 1)
+    return mi355q_splitk_add_rms_norm(out, residual, p.partial, mp.splits, bias, norm_weight, epsilon, M, N, act_dtype, stream);
+  return mi355q_fused_add_rms_norm(out, N, residual, norm_weight, epsilon, M, N, act_dtype, stream);
 }

@@ -213,12 +213,23 @@ class LlamaRunner:
                 torch.distributed.all_reduce(x, group=self.tp_group)
         return x
 
-    def _layer(self, L, li, h, residual, positions, slot_mapping, attend):
+    def _tail_norm_ok(self, T, lin) -> bool:
+        """A row-parallel projection whose K-slice sums, residual add and the following RMSNorm can run
+        as one kernel: the tiled kernel's token range, whole projection on this rank."""
+        return (self.quant != "none" and self.tp_size == 1 and ops.MM_MIN_TOKENS <= T <= ops.MM_MAX_TOKENS
+                and ops._mm_supported(lin.w))
+
+    def _layer(self, L, li, h, residual, positions, slot_mapping, attend, normed=False, next_norm=None):
+        """One decoder layer.  `normed`: h already is RMSNorm(residual) (the previous layer's down
+        projection finished it).  `next_norm`: weight of the norm that follows this layer; when the
+        down projection can finish that norm too, the third return value is True."""
         cfg, D = self.cfg, self.cfg.head_dim
         T = h.shape[0]
         # small token counts: the add+RMSNorm runs in the prologue of the GEMM that consumes it
         fuse_norm = self.quant != "none" and T <= FUSE_NORM_MAX_TOKENS
-        if fuse_norm:
+        if normed:
+            qkv = L["qkv"](h)
+        elif fuse_norm:
             qkv, residual = ops.w4a16_gemm_add_rms_norm(h, residual, L["ln1"], cfg.rms_eps, L["qkv"].w)
         else:
             if residual is None:
@@ -242,7 +253,18 @@ class LlamaRunner:
             ops.rope_and_cache(positions, q, k, v, D, self.cos_sin, True, self.kc[li], self.vc[li], slot_mapping,
                                self.kv_cache_dtype, self.k_scale, self.v_scale)
             attend(li, q.view(T, self.heads, D), attn)
-        o = self._all_reduce(L["o"](attn.view(T, qs)))
+        o_normed = self._tail_norm_ok(T, L["o"]) if self.quant != "none" else False
+        if o_normed:   # o_proj, residual add and the post-attention norm
+            o = ops.w4a16_mm_add_rms_norm(attn.view(T, qs), L["o"].w, residual, L["ln2"], cfg.rms_eps)
+        else:
+            o = self._all_reduce(L["o"](attn.view(T, qs)))
+        tail = next_norm is not None and self._tail_norm_ok(T, L["down"]) if self.quant != "none" else False
+
+        def down(act, **kw):
+            if tail:   # down_proj, residual add and the norm that follows this layer
+                return ops.w4a16_mm_add_rms_norm(act, L["down"].w, residual, next_norm, cfg.rms_eps), residual, True
+            return self._all_reduce(L["down"](act, **kw)), residual, False
+
         if self.quant != "none" and L["gate_up"].w.pair_halves:
             gu_w = L["gate_up"].w
             tiled = ops.MM_MIN_TOKENS <= T <= ops.MM_MAX_TOKENS and ops._mm_supported(gu_w)
@@ -251,23 +273,31 @@ class LlamaRunner:
                 if fuse_norm:
                     act, residual = ops.w4a16_gate_up_silu(o, residual, L["ln2"], cfg.rms_eps, gu_w)
                 else:
-                    ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
+                    if not o_normed:
+                        ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
                     if tiled:
                         act = ops.w4a16_mm(o, gu_w, silu_pairs=True)
                     else:
                         act, _ = ops.w4a16_gate_up_silu(o, None, None, cfg.rms_eps, gu_w, add_norm=False)
-                d = self._all_reduce(L["down"](act))
-                return d, residual
+                return down(act)
         if fuse_norm:
             gu, residual = ops.w4a16_gemm_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps, L["gate_up"].w)
         else:
-            ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
+            if not o_normed:
+                ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
             gu = L["gate_up"](o)
-        d = self._all_reduce(L["down"](gu, fuse_silu_mul=True))
-        return d, residual
+        if tail:   # the fused tail takes the activation itself
+            act = torch.empty((T, gu.shape[1] // 2), dtype=gu.dtype, device=gu.device)
+            ops.silu_and_mul(act, gu)
+            return down(act)
+        return down(gu, fuse_silu_mul=True)
 
-    def _logits(self, h, residual):
-        ops.fused_add_rms_norm(h, residual, self.norm, self.cfg.rms_eps)
+    def _next_norm(self, li):
+        return self.layers[li + 1]["ln1"] if li + 1 < len(self.layers) else self.norm
+
+    def _logits(self, h, residual, normed=False):
+        if not normed:
+            ops.fused_add_rms_norm(h, residual, self.norm, self.cfg.rms_eps)
         M = h.shape[0]
         logits = ops.linear_skinny(h, self.lm_head) if M <= 16 else torch.nn.functional.linear(h, self.lm_head)
         if self.tp_size > 1:
@@ -301,10 +331,12 @@ class LlamaRunner:
 
         h = self.embed.index_select(0, tokens)
         residual = None
+        normed = False
         for li, L in enumerate(self.layers):
-            h, residual = self._layer(L, li, h, residual, positions, slot_mapping, attend)
+            h, residual, normed = self._layer(L, li, h, residual, positions, slot_mapping, attend, normed,
+                                              self._next_norm(li))
         last = torch.arange(T - 1, B * T, T, device=dev)
-        logits = self._logits(h.index_select(0, last), residual.index_select(0, last))
+        logits = self._logits(h.index_select(0, last), residual.index_select(0, last), normed)
         ids = ops.argmax(logits)
         self.tokens[:B] = ids
         self.positions[:B] = T
@@ -327,9 +359,11 @@ class LlamaRunner:
 
         h = self.embed.index_select(0, self.tokens)
         residual = None
+        normed = False
         for li, L in enumerate(self.layers):
-            h, residual = self._layer(L, li, h, residual, self.positions, slot_mapping, attend)
-        ops.argmax(self._logits(h, residual), out=self.tokens)
+            h, residual, normed = self._layer(L, li, h, residual, self.positions, slot_mapping, attend, normed,
+                                              self._next_norm(li))
+        ops.argmax(self._logits(h, residual, normed), out=self.tokens)
         self.positions.add_(1)
         self.seq_lens.add_(1)
 

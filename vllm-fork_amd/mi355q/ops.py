@@ -197,6 +197,31 @@ def w4a16_mm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, sil
     return out
 
 
+def w4a16_mm_add_rms_norm(x: torch.Tensor, w: PackedW4, residual: torch.Tensor, norm_weight: torch.Tensor,
+                          epsilon: float, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """w4a16_mm(x, w, bias) followed by fused_add_rms_norm(result, residual): `residual` is updated in
+    place and the normalised rows are returned.  With K-slices the slice sums, the residual add and
+    the norm are one kernel (no separate reduction launch)."""
+    _need_cuda(x, w.packed, residual, norm_weight)
+    if x.dim() != 2 or x.shape[1] != w.K or x.stride(1) != 1:
+        raise RuntimeError(f"w4a16_mm_add_rms_norm: input must be [tokens, {w.K}] with unit inner stride")
+    if x.dtype != w.scales.dtype or residual.dtype != x.dtype or norm_weight.dtype != x.dtype:
+        raise RuntimeError("w4a16_mm_add_rms_norm: activation, residual, norm weight and scales must share a dtype")
+    M = x.shape[0]
+    if residual.shape != (M, w.N) or not residual.is_contiguous() or norm_weight.numel() != w.N:
+        raise RuntimeError(f"w4a16_mm_add_rms_norm: residual must be contiguous [{M}, {w.N}] and the norm weight [{w.N}]")
+    L = _lib.lib()
+    out = torch.empty((M, w.N), dtype=x.dtype, device=x.device)
+    need = L.mi355q_w4a16_mm_workspace_bytes(M, w.N, w.K, w.G, w.tile)
+    ws = _workspace(x.device, need + COUNTER_BYTES) if need else None
+    check(L.mi355q_w4a16_mm_add_rms_norm(
+        x.data_ptr(), x.stride(0), w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc), _ptr(bias), residual.data_ptr(),
+        norm_weight.data_ptr(), epsilon, out.data_ptr(), M, w.N, w.K, w.G, w.tile, _dt(x),
+        ws.data_ptr() + COUNTER_BYTES if ws is not None else None, ws.numel() - COUNTER_BYTES if ws is not None else 0,
+        _stream()))
+    return out
+
+
 def w4a16_gemm_add_rms_norm(x: torch.Tensor, residual: torch.Tensor | None, norm_weight: torch.Tensor | None,
                             epsilon: float, w: PackedW4, bias: torch.Tensor | None = None, split_k: int = 0):
     """fused_add_rms_norm(x, residual) followed by the W4A16 GEMM, in one kernel.
