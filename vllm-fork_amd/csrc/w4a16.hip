@@ -1680,6 +1680,9 @@ __global__ __launch_bounds__(256) void w4a16_mm_reduce_kernel(const MmParams p) 
 }
 
 constexpr int MM_RT = 4;
+// 32 rows or fewer (decode batches beyond the GEMV kernels' reach): 32-row tiles, half the matrix-core
+// and accumulator work per weight chunk of the 64-row tile
+static inline int mm_rt(int M) { return M <= 32 && !getenv("MI355Q_MM_RT4") ? 2 : MM_RT; }
 
 struct MmPlan {
   bool ok;
@@ -1696,7 +1699,8 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw) {
   const int bw = 4 * spw * sw;
   if (N % bw) return mp;
   const int chunks = K / 128;
-  const long tiles = (long)(N / bw) * ((M + 16 * MM_RT - 1) / (16 * MM_RT));
+  const int bm = 16 * mm_rt(M);
+  const long tiles = (long)(N / bw) * ((M + bm - 1) / bm);
   int s = 1;
   while (tiles * s < 200 && s < 16 && chunks % (s * 2) == 0 && chunks / (s * 2) >= 2) s *= 2;
   if (tiles * s < 200) {   // odd factors of the chunk count (K = 14336 = 128 * 112 = 128 * 16 * 7)
@@ -1711,14 +1715,20 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw) {
 template <typename DT>
 static int launch_mm(const MmParams& p, const MmPlan& mp, hipStream_t stream, bool reduce = true) {
   const int bw = 4 * mp.spw * 16 * mp.ns;
-  dim3 grid(p.N / bw, (p.M + 16 * MM_RT - 1) / (16 * MM_RT), p.splits), block(256);
+  const int rt = mm_rt(p.M);
+  dim3 grid(p.N / bw, (p.M + 16 * rt - 1) / (16 * rt), p.splits), block(256);
+#define MI355Q_MM_RT(NS_, SPW_, RT_)                                                                       \
+  {                                                                                                       \
+    if (p.zc) hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, RT_, true>), grid, block, 0, stream, p);    \
+    else hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, RT_, false>), grid, block, 0, stream, p);        \
+  }
 #define MI355Q_MM(NS_, SPW_)                                                                              \
   if (mp.ns == NS_) {                                                                                     \
-    if (p.zc) hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, MM_RT, true>), grid, block, 0, stream, p);  \
-    else hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, MM_RT, false>), grid, block, 0, stream, p);      \
+    if (rt == 2) MI355Q_MM_RT(NS_, SPW_, 2) else MI355Q_MM_RT(NS_, SPW_, MM_RT)                            \
   }
   MI355Q_MM(1, 4) else MI355Q_MM(2, 2) else MI355Q_MM(4, 1) else MI355Q_MM(7, 1)
 #undef MI355Q_MM
+#undef MI355Q_MM_RT
   if (int e = check_launch("w4a16_mm_kernel")) return e;
   if (p.splits > 1 && reduce) {
     const size_t items = (size_t)p.M * (p.N >> 2);
