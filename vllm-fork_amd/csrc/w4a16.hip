@@ -1682,7 +1682,10 @@ __global__ __launch_bounds__(256) void w4a16_mm_reduce_kernel(const MmParams p) 
 constexpr int MM_RT = 4;
 // 32 rows or fewer (decode batches beyond the GEMV kernels' reach): 32-row tiles, half the matrix-core
 // and accumulator work per weight chunk of the 64-row tile
-static inline int mm_rt(int M) { return M <= 32 && !getenv("MI355Q_MM_RT4") ? 2 : MM_RT; }
+static inline int mm_rt(int M) {
+  static const int rt2_max = getenv("MI355Q_MM_RT2_MAX") ? atoi(getenv("MI355Q_MM_RT2_MAX")) : 32;
+  return M <= rt2_max ? 2 : MM_RT;
+}
 
 struct MmPlan {
   bool ok;
