@@ -199,6 +199,18 @@ int mi355q_w4a16_mm_add_rms_norm(const void* a, int lda, const void* packed, con
                                  const void* norm_weight, float epsilon, void* out, int M, int N,
                                  int K, int G, int tile, int act_dtype, void* workspace,
                                  size_t workspace_bytes, mi355q_stream_t stream);
+/* mi355q_w4a16_mm for the fused qkv projection of prompt tokens followed by mi355q_rope_and_cache on
+ * its q / k / v column ranges (QKVParallelLinear -> rotary_emb -> cache update,
+ * vllm/model_executor/models/llama.py:218-226); K-slices are merged by mi355q_splitk_rope_and_cache.
+ * Same workspace as mi355q_w4a16_mm. */
+int mi355q_w4a16_mm_rope_and_cache(const void* a, int lda, const void* packed, const void* scales,
+                                   const void* zc, const void* bias, void* qkv, int M, int N, int K, int G,
+                                   int tile, int act_dtype, void* workspace, size_t workspace_bytes,
+                                   const int64_t* positions, int head_size, int num_heads, int num_kv_heads,
+                                   const void* cos_sin_cache, int rot_dim, int cache_dtype, int is_neox,
+                                   void* key_cache, void* value_cache, const int64_t* slot_mapping,
+                                   int block_size, int64_t block_stride, int kv_fp8, const float* k_scale,
+                                   const float* v_scale, mi355q_stream_t stream);
 
 /*
  * gate_up projection with SiluAndMul in its epilogue, for weights repacked with
@@ -370,6 +382,17 @@ int mi355q_rope_and_cache(const int64_t* positions, void* query, int64_t query_s
                           const int64_t* slot_mapping, int num_tokens, int block_size,
                           int64_t block_stride, int dtype, int kv_fp8, const float* k_scale,
                           const float* v_scale, mi355q_stream_t stream);
+/* The tail of a fused qkv projection computed in K-slices: partial fp32 [splits][T][N],
+ * N = (heads + 2 kv_heads) * head_size.  Row t of qkv = round(sum of the slices) (+ bias, rounded
+ * again), NeoX RoPE over the whole head on its q and k heads, k and v written to the paged cache: the
+ * slice merge of mi355q_w4a16_mm followed by mi355q_rope_and_cache, in one launch.  No counterpart in
+ * the reference (it runs gptq_gemm, rotary_embedding and reshape_and_cache one after the other). */
+int mi355q_splitk_rope_and_cache(const float* partial, int splits, const void* bias, void* qkv,
+                                 const int64_t* positions, int head_size, int num_heads, int num_kv_heads,
+                                 const void* cos_sin_cache, int cache_dtype, void* key_cache,
+                                 void* value_cache, const int64_t* slot_mapping, int num_tokens,
+                                 int block_size, int64_t block_stride, int dtype, int kv_fp8,
+                                 const float* k_scale, const float* v_scale, mi355q_stream_t stream);
 /* dst = fp8 -> dtype or dtype -> fp8 element-wise with scale.  Replaces
  * ops.convert_fp8 (vllm/_custom_ops.py:2908; cache_kernels.cu:1003-1060). */
 int mi355q_convert_fp8(void* dst, const void* src, int64_t n, float scale, int dtype,

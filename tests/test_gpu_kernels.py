@@ -206,6 +206,50 @@ def test_w4a16_mm_add_rms_norm_equals_the_two_steps(M, K, N, with_bias):
     np.testing.assert_allclose(f32(to_bits(out)), f32(ref_x), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("M,K,nh,nkv,head,with_bias", [(128, 4096, 32, 8, 128, False), (40, 1024, 8, 4, 64, True),
+                                                        (300, 2048, 14, 1, 128, False)])
+def test_w4a16_mm_rope_and_cache_equals_the_sequence(fp8, M, K, nh, nkv, head, with_bias):
+    """qkv projection + RoPE + cache write as one call = w4a16_mm, then rope_and_cache on the column
+    ranges: identical bits in qkv and in both caches (K-slices merged in the same order)."""
+    rng = np.random.default_rng(M + K + nh)
+    G, bs, max_pos = 128, 16, 512
+    N = (nh + 2 * nkv) * head
+    nblk = (M + bs - 1) // bs + 2
+    x = 16 if fp8 else 8
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    a = to_dev(orc.f32_to_h16(0.25 * rng.standard_normal((M, K)).astype(np.float32)))
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N))).astype(np.float32))
+    bias = to_dev(orc.f32_to_h16(rng.standard_normal(N).astype(np.float32))) if with_bias else None
+    w = ops.w4a16_repack(i32(orc.gptq_pack(q)), to_dev(s), None, G)
+    pos = torch.from_numpy(rng.integers(0, max_pos, size=M).astype(np.int64)).to(DEV)
+    inv = 1.0 / (10000.0 ** (np.arange(0, head, 2, dtype=np.float32) / head))
+    fr = np.arange(max_pos, dtype=np.float32)[:, None] * inv[None, :]
+    cache = to_dev(orc.f32_to_h16(np.concatenate([np.cos(fr), np.sin(fr)], axis=1).astype(np.float32)))
+    slots_np = rng.permutation(nblk * bs)[:M].astype(np.int64)
+    slots_np[M // 2] = -1
+    slots = torch.from_numpy(slots_np).to(DEV)
+    tdt = torch.uint8 if fp8 else torch.bfloat16
+    kvd = "fp8" if fp8 else "auto"
+    ks = torch.tensor(0.05 if fp8 else 1.0, dtype=torch.float32, device=DEV)
+    vs = torch.tensor(0.02 if fp8 else 1.0, dtype=torch.float32, device=DEV)
+
+    def caches():
+        return (torch.zeros((nblk, nkv, head // x, bs, x), dtype=tdt, device=DEV),
+                torch.zeros((nblk, nkv, head, bs), dtype=tdt, device=DEV))
+
+    kc1, vc1 = caches()
+    ref = ops.w4a16_mm(a, w, bias=bias)
+    qs, ksz = nh * head, nkv * head
+    ops.rope_and_cache(pos, ref[:, :qs], ref[:, qs:qs + ksz], ref[:, qs + ksz:], head, cache, True, kc1, vc1, slots, kvd,
+                       ks, vs)
+    kc2, vc2 = caches()
+    got = ops.w4a16_mm_rope_and_cache(a, w, pos, head, nh, nkv, cache, True, kc2, vc2, slots, kvd, ks, vs, bias=bias)
+    assert torch.equal(got, ref)
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+    assert int((kc2 != 0).sum()) > 0
+
+
 def test_w4a16_mm_silu_pairs_and_routing(monkeypatch):
     """pair_halves weight + SiLU epilogue = silu_and_mul of the plain projection; w4a16_gemm routes
     17..1024 tokens to the tiled kernel and refuses nothing it used to serve."""

@@ -375,6 +375,113 @@ __global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uin
   }
 }
 
+// The fused qkv projection finished in one pass over the token: K-slice sums of the fp32 partial tiles
+// (slice order, rounded to the activation dtype, bias added to the rounded value), NeoX RoPE over the
+// whole head on q and k, the rotated row written to `qkv` and k, v to the paged cache.  Equal, bit for
+// bit, to the slice-merge kernel followed by rope_and_cache_kernel.  Four pairs per work item.
+template <typename DT, bool FP8>
+__global__ __launch_bounds__(1024) void splitk_rope_and_cache_kernel(
+    const float* __restrict__ partial, int splits, size_t split_stride, const uint16_t* __restrict__ bias,
+    uint16_t* __restrict__ qkv, int N, const int64_t* __restrict__ positions, int head, int nh, int nkv,
+    const void* __restrict__ cache, int cache_dtype, void* __restrict__ kc, void* __restrict__ vc,
+    const int64_t* __restrict__ slot_mapping, int bs, int64_t block_stride, const float* __restrict__ k_scale,
+    const float* __restrict__ v_scale) {
+  const int t = blockIdx.x;
+  const int e = head / 2, q4 = e / 4;
+  const size_t cbase = (size_t)positions[t] * head;
+  const int64_t slot = slot_mapping[t];
+  const int64_t b = slot / bs, o = slot % bs;
+  constexpr int X = FP8 ? 16 : 8;
+  const float ks = FP8 ? *k_scale : 1.f, vs = FP8 ? *v_scale : 1.f;
+  const float* prow = partial + (size_t)t * N;
+  uint16_t* orow = qkv + (size_t)t * N;
+  auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
+  auto hi = [](uint32_t u) { return DT::to_f32((uint16_t)(u >> 16)); };
+  // two columns blocks of four channels summed together (the second is a dummy repeat for v items)
+  auto merge2 = [&](int ca, int cb, float (&va)[4], float (&vb)[4]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(prow + ca), c = *reinterpret_cast<const f32x4*>(prow + cb);
+    for (int sp0 = 1; sp0 < splits; sp0 += 4) {
+      f32x4 ta[4], tc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const size_t base = (size_t)min(sp0 + u, splits - 1) * split_stride;
+        ta[u] = *reinterpret_cast<const f32x4*>(prow + base + ca);
+        tc[u] = *reinterpret_cast<const f32x4*>(prow + base + cb);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (sp0 + u < splits) { a += ta[u]; c += tc[u]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      va[j] = DT::to_f32(DT::from_f32(a[j]));
+      vb[j] = DT::to_f32(DT::from_f32(c[j]));
+    }
+    if (bias) {
+      const u32x2 ba = *reinterpret_cast<const u32x2*>(bias + ca), bb = *reinterpret_cast<const u32x2*>(bias + cb);
+      const float fa[4] = {lo(ba[0]), hi(ba[0]), lo(ba[1]), hi(ba[1])}, fb[4] = {lo(bb[0]), hi(bb[0]), lo(bb[1]), hi(bb[1])};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        va[j] = DT::to_f32(DT::from_f32(va[j] + fa[j]));
+        vb[j] = DT::to_f32(DT::from_f32(vb[j] + fb[j]));
+      }
+    }
+  };
+  auto put_k4 = [&](int h, int d, const uint16_t (&bits)[4]) {
+    const size_t ki = (size_t)b * block_stride + (((size_t)h * (head / X) + d / X) * bs + o) * X + d % X;
+    if constexpr (FP8) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) w |= (uint32_t)f32_to_fp8(DT::to_f32(bits[j]) / ks) << (8 * j);
+      *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(kc) + ki) = w;
+    } else {
+      *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(kc) + ki) =
+          u32x2{(uint32_t)bits[0] | ((uint32_t)bits[1] << 16), (uint32_t)bits[2] | ((uint32_t)bits[3] << 16)};
+    }
+  };
+  const int rope_items = (nh + nkv) * q4, v_items = nkv * head / 4;
+  for (int item = threadIdx.x; item < rope_items + v_items; item += blockDim.x) {
+    if (item < rope_items) {
+      const int h = item / q4, i4 = (item - h * q4) * 4;
+      const int cx = h * head + i4, cy = cx + e;
+      float x[4], y[4];
+      merge2(cx, cy, x, y);
+      uint16_t xo[4], yo[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float c = load_cache(cache, cbase + i4 + j, cache_dtype);
+        const float s = load_cache(cache, cbase + e + i4 + j, cache_dtype);
+        xo[j] = DT::from_f32(x[j] * c - y[j] * s);
+        yo[j] = DT::from_f32(y[j] * c + x[j] * s);
+      }
+      *reinterpret_cast<u32x2*>(orow + cx) = u32x2{(uint32_t)xo[0] | ((uint32_t)xo[1] << 16), (uint32_t)xo[2] | ((uint32_t)xo[3] << 16)};
+      *reinterpret_cast<u32x2*>(orow + cy) = u32x2{(uint32_t)yo[0] | ((uint32_t)yo[1] << 16), (uint32_t)yo[2] | ((uint32_t)yo[3] << 16)};
+      if (h >= nh && slot >= 0) {
+        put_k4(h - nh, i4, xo);
+        put_k4(h - nh, e + i4, yo);
+      }
+    } else {
+      const int j4 = (item - rope_items) * 4;          // value channel h * head + d
+      const int col = (nh + nkv) * head + j4;
+      float v[4], dummy[4];
+      merge2(col, col, v, dummy);
+      uint16_t vb[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) vb[j] = DT::from_f32(v[j]);
+      *reinterpret_cast<u32x2*>(orow + col) = u32x2{(uint32_t)vb[0] | ((uint32_t)vb[1] << 16), (uint32_t)vb[2] | ((uint32_t)vb[3] << 16)};
+      if (slot >= 0) {
+        const int h = j4 / head, d = j4 - h * head;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const size_t vi = (size_t)b * block_stride + ((size_t)h * head + d + j) * bs + o;
+          if constexpr (FP8) reinterpret_cast<uint8_t*>(vc)[vi] = f32_to_fp8(DT::to_f32(vb[j]) / vs);
+          else reinterpret_cast<uint16_t*>(vc)[vi] = vb[j];
+        }
+      }
+    }
+  }
+}
+
 template <typename DT>
 __global__ void convert_fp8_kernel(void* __restrict__ dst, const void* __restrict__ src, int64_t n,
                                    float scale, int to_fp8) {
@@ -728,6 +835,38 @@ extern "C" int mi355q_rope_and_cache(const int64_t* positions, void* query, int6
   if (kv_fp8) { MI355Q_RC(true); } else { MI355Q_RC(false); }
 #undef MI355Q_RC
   return check_launch("rope_and_cache_kernel");
+}
+
+extern "C" int mi355q_splitk_rope_and_cache(const float* partial, int splits, const void* bias, void* qkv,
+                                            const int64_t* positions, int head_size, int num_heads,
+                                            int num_kv_heads, const void* cos_sin_cache, int cache_dtype,
+                                            void* key_cache, void* value_cache, const int64_t* slot_mapping,
+                                            int num_tokens, int block_size, int64_t block_stride, int dtype,
+                                            int kv_fp8, const float* k_scale, const float* v_scale,
+                                            mi355q_stream_t stream) {
+  if (int e = check_h16(dtype, "splitk_rope_and_cache")) return e;
+  if (num_tokens == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(partial && qkv && positions && cos_sin_cache && key_cache && value_cache && slot_mapping && splits >= 1,
+                 "splitk_rope_and_cache: bad arguments");
+  MI355Q_REQUIRE(head_size % 16 == 0 && num_heads > 0 && num_kv_heads > 0 && block_size > 0,
+                 "splitk_rope_and_cache: head_size %d must be a multiple of 16", head_size);
+  MI355Q_REQUIRE(cache_dtype >= MI355Q_BF16 && cache_dtype <= MI355Q_FP32, "splitk_rope_and_cache: bad cache dtype");
+  MI355Q_REQUIRE((((uintptr_t)partial) & 15) == 0 && (((uintptr_t)qkv | (uintptr_t)bias | (uintptr_t)key_cache) & 7) == 0,
+                 "splitk_rope_and_cache: partial tiles must be 16-byte aligned, qkv / bias / cache 8-byte aligned");
+  if (kv_fp8) MI355Q_REQUIRE(k_scale && v_scale, "splitk_rope_and_cache: fp8 cache needs k_scale/v_scale");
+  const int N = (num_heads + 2 * num_kv_heads) * head_size;
+  const int items = (num_heads + num_kv_heads) * head_size / 8 + num_kv_heads * head_size / 4;
+  const int threads = items >= 1024 ? 1024 : (items + 63) / 64 * 64;
+  hipStream_t s = (hipStream_t)stream;
+#define MI355Q_SRC(F8)                                                                                              \
+  DISPATCH_H16(dtype, hipLaunchKernelGGL((splitk_rope_and_cache_kernel<DT, F8>), dim3(num_tokens), dim3(threads), 0, s, \
+                                         partial, splits, (size_t)num_tokens * N, (const uint16_t*)bias,              \
+                                         (uint16_t*)qkv, N, positions, head_size, num_heads, num_kv_heads,            \
+                                         cos_sin_cache, cache_dtype, key_cache, value_cache, slot_mapping,             \
+                                         block_size, block_stride, k_scale, v_scale))
+  if (kv_fp8) { MI355Q_SRC(true); } else { MI355Q_SRC(false); }
+#undef MI355Q_SRC
+  return check_launch("splitk_rope_and_cache_kernel");
 }
 
 extern "C" int mi355q_convert_fp8(void* dst, const void* src, int64_t n, float scale, int dtype,

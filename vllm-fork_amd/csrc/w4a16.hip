@@ -2147,3 +2147,55 @@ extern "C" int mi355q_w4a16_mm_add_rms_norm(const void* a, int lda, const void* 
     return mi355q_splitk_add_rms_norm(out, residual, p.partial, mp.splits, bias, norm_weight, epsilon, M, N, act_dtype, stream);
   return mi355q_fused_add_rms_norm(out, N, residual, norm_weight, epsilon, M, N, act_dtype, stream);
 }
+
+/* The fused qkv projection of prompt tokens: c = a W (+ bias), NeoX RoPE on the q and k heads of c (in
+ * place), rotated k and v written to the paged cache.  With K-slices, the slice sums, the rotation and
+ * the cache write are one kernel; otherwise (or for GPT-J pairing / partial rotary) the plain sequence
+ * mi355q_w4a16_mm -> mi355q_rope_and_cache runs. */
+extern "C" int mi355q_w4a16_mm_rope_and_cache(const void* a, int lda, const void* packed, const void* scales,
+                                              const void* zc, const void* bias, void* qkv, int M, int N, int K,
+                                              int G, int tile, int act_dtype, void* workspace,
+                                              size_t workspace_bytes, const int64_t* positions, int head_size,
+                                              int num_heads, int num_kv_heads, const void* cos_sin_cache,
+                                              int rot_dim, int cache_dtype, int is_neox, void* key_cache,
+                                              void* value_cache, const int64_t* slot_mapping, int block_size,
+                                              int64_t block_stride, int kv_fp8, const float* k_scale,
+                                              const float* v_scale, mi355q_stream_t stream) {
+  MI355Q_REQUIRE(head_size > 0 && num_heads > 0 && num_kv_heads > 0 && N == (num_heads + 2 * num_kv_heads) * head_size,
+                 "w4a16_mm_rope_and_cache: N = %d is not (heads + 2 kv_heads) * head_size", N);
+  if (G <= 0) G = K;
+  const MmPlan mp = plan_mm(M > 0 ? M : 1, N, K, G, tile);
+  const bool fused = mp.ok && mp.splits > 1 && is_neox && rot_dim == head_size && head_size % 16 == 0;
+  if (!fused) {
+    if (int e = mi355q_w4a16_mm(a, lda, packed, scales, zc, bias, qkv, M, N, K, G, tile, act_dtype, 0, workspace,
+                                workspace_bytes, stream)) return e;
+    uint16_t* q = (uint16_t*)qkv;
+    return mi355q_rope_and_cache(positions, q, N, q + (size_t)num_heads * head_size, N,
+                                 q + (size_t)(num_heads + num_kv_heads) * head_size, N, head_size, num_heads,
+                                 num_kv_heads, cos_sin_cache, rot_dim, cache_dtype, is_neox, key_cache, value_cache,
+                                 slot_mapping, M, block_size, block_stride, act_dtype, kv_fp8, k_scale, v_scale, stream);
+  }
+  if (int e = check_shape(K, N, G)) return e;
+  if (int e = check_tile(tile, K, G, N)) return e;
+  MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "w4a16_mm_rope_and_cache: act_dtype must be bf16 or fp16");
+  if (M == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(a && packed && scales && qkv && M > 0, "w4a16_mm_rope_and_cache: bad arguments");
+  MI355Q_REQUIRE(lda % 8 == 0 && lda >= K, "w4a16_mm_rope_and_cache: row stride %d must be a multiple of 8 and cover the row", lda);
+  MI355Q_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)scales & 15) == 0 &&
+                     ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)zc & 15) == 0 && ((uintptr_t)bias & 7) == 0,
+                 "w4a16_mm_rope_and_cache: pointers must be 16-byte aligned");
+  MI355Q_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "w4a16_mm_rope_and_cache: K-slices need a 16-byte aligned workspace");
+  if (workspace_bytes < mp.ws) return set_error(MI355Q_ENOSPACE, "w4a16_mm_rope_and_cache: workspace %zu B < %zu B", workspace_bytes, mp.ws);
+  MmParams p;
+  p.x = (const uint16_t*)a; p.ldx = lda; p.wp = (const u32x4*)packed;
+  p.scales = (const uint16_t*)scales; p.zc = (const uint16_t*)zc; p.bias = (const uint16_t*)bias;
+  p.out = (uint16_t*)qkv; p.partial = (float*)workspace;
+  p.M = M; p.N = N; p.K = K; p.chunks = K / 128; p.gchunks = G / 128;
+  p.splits = mp.splits; p.cps = p.chunks / mp.splits; p.epi_silu = 0;
+  const int e = act_dtype == MI355Q_BF16 ? launch_mm<BF16>(p, mp, (hipStream_t)stream, false)
+                                         : launch_mm<FP16>(p, mp, (hipStream_t)stream, false);
+  if (e) return e;
+  return mi355q_splitk_rope_and_cache(p.partial, mp.splits, bias, qkv, positions, head_size, num_heads, num_kv_heads,
+                                      cos_sin_cache, cache_dtype, key_cache, value_cache, slot_mapping, M, block_size,
+                                      block_stride, act_dtype, kv_fp8, k_scale, v_scale, stream);
+}

@@ -71,6 +71,11 @@ _SIGS = {
     "mi355q_rope_and_cache": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_int,
                                       c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_int, c_int, c_vp, c_vp,
                                       c_vp]),
+    "mi355q_splitk_rope_and_cache": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp,
+                                             c_vp, c_int, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    "mi355q_w4a16_mm_rope_and_cache": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
+                                               c_int, c_vp, c_sz, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int,
+                                               c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
     "mi355q_convert_fp8": (c_int, [c_vp, c_vp, c_i64, c_f32, c_int, c_int, c_vp]),
     "mi355q_paged_attention": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_int,
                                        c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_int,

@@ -227,8 +227,19 @@ class LlamaRunner:
         T = h.shape[0]
         # small token counts: the add+RMSNorm runs in the prologue of the GEMM that consumes it
         fuse_norm = self.quant != "none" and T <= FUSE_NORM_MAX_TOKENS
+        # prompt tokens on the tiled kernel: projection, RoPE and cache write as one op
+        qkv_tail = (attend is not None and self.quant != "none" and ops.MM_MIN_TOKENS <= T <= ops.MM_MAX_TOKENS
+                    and ops._mm_supported(L["qkv"].w))
+
+        def qkv_proj(x):
+            if qkv_tail:
+                return ops.w4a16_mm_rope_and_cache(x, L["qkv"].w, positions, D, self.heads, self.kv_heads, self.cos_sin,
+                                                   True, self.kc[li], self.vc[li], slot_mapping, self.kv_cache_dtype,
+                                                   self.k_scale, self.v_scale)
+            return L["qkv"](x)
+
         if normed:
-            qkv = L["qkv"](h)
+            qkv = qkv_proj(h)
         elif fuse_norm:
             qkv, residual = ops.w4a16_gemm_add_rms_norm(h, residual, L["ln1"], cfg.rms_eps, L["qkv"].w)
         else:
@@ -239,7 +250,7 @@ class LlamaRunner:
             else:
                 ops.fused_add_rms_norm(h, residual, L["ln1"], cfg.rms_eps)
                 x = h
-            qkv = L["qkv"](x)
+            qkv = qkv_proj(x)
         qs, ks = self.heads * D, self.kv_heads * D
         attn = torch.empty((T, self.heads, D), dtype=h.dtype, device=h.device)
         if attend is None:
@@ -250,8 +261,9 @@ class LlamaRunner:
                                        self.max_seq_len, self.kv_cache_dtype, self.k_scale, self.v_scale)
         else:
             q, k, v = qkv[:, :qs], qkv[:, qs:qs + ks], qkv[:, qs + ks:]
-            ops.rope_and_cache(positions, q, k, v, D, self.cos_sin, True, self.kc[li], self.vc[li], slot_mapping,
-                               self.kv_cache_dtype, self.k_scale, self.v_scale)
+            if not qkv_tail:
+                ops.rope_and_cache(positions, q, k, v, D, self.cos_sin, True, self.kc[li], self.vc[li], slot_mapping,
+                                   self.kv_cache_dtype, self.k_scale, self.v_scale)
             attend(li, q.view(T, self.heads, D), attn)
         o_normed = self._tail_norm_ok(T, L["o"]) if self.quant != "none" else False
         if o_normed:   # o_proj, residual add and the post-attention norm

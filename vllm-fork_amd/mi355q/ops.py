@@ -222,6 +222,40 @@ def w4a16_mm_add_rms_norm(x: torch.Tensor, w: PackedW4, residual: torch.Tensor, 
     return out
 
 
+def w4a16_mm_rope_and_cache(x: torch.Tensor, w: PackedW4, positions: torch.Tensor, head_size: int, num_heads: int,
+                            num_kv_heads: int, cos_sin_cache: torch.Tensor, is_neox: bool, key_cache: torch.Tensor,
+                            value_cache: torch.Tensor, slot_mapping: torch.Tensor, kv_cache_dtype: str, k_scale, v_scale,
+                            bias: torch.Tensor | None = None) -> torch.Tensor:
+    """The fused qkv projection of prompt tokens, w4a16_mm(x, w, bias), followed by rope_and_cache on its
+    q / k / v column ranges; returns qkv [tokens, (heads + 2 kv_heads) * head] with q and k rotated.  When
+    the projection is computed in K-slices, their merge, the rotation and the cache write are one launch."""
+    _need_cuda(x, w.packed, positions, cos_sin_cache, key_cache, value_cache, slot_mapping)
+    if x.dim() != 2 or x.shape[1] != w.K or x.stride(1) != 1:
+        raise RuntimeError(f"w4a16_mm_rope_and_cache: input must be [tokens, {w.K}] with unit inner stride")
+    if x.dtype != w.scales.dtype:
+        raise RuntimeError(f"activation dtype {x.dtype} != scales dtype {w.scales.dtype}")
+    M = x.shape[0]
+    if w.N != (num_heads + 2 * num_kv_heads) * head_size:
+        raise RuntimeError(f"w4a16_mm_rope_and_cache: N = {w.N} is not (heads + 2 kv_heads) * head_size")
+    if positions.dtype != torch.int64 or slot_mapping.dtype != torch.int64 or positions.numel() != M or \
+            slot_mapping.numel() != M:
+        raise RuntimeError("w4a16_mm_rope_and_cache: positions and slot_mapping must be int64, one entry per token")
+    if key_cache.shape[1] != num_kv_heads or value_cache.shape[1] != num_kv_heads:
+        raise RuntimeError("w4a16_mm_rope_and_cache: cache head count differs from num_kv_heads")
+    L = _lib.lib()
+    qkv = torch.empty((M, w.N), dtype=x.dtype, device=x.device)
+    need = L.mi355q_w4a16_mm_workspace_bytes(M, w.N, w.K, w.G, w.tile)
+    ws = _workspace(x.device, need + COUNTER_BYTES) if need else None
+    check(L.mi355q_w4a16_mm_rope_and_cache(
+        x.data_ptr(), x.stride(0), w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc), _ptr(bias), qkv.data_ptr(),
+        M, w.N, w.K, w.G, w.tile, _dt(x), ws.data_ptr() + COUNTER_BYTES if ws is not None else None,
+        ws.numel() - COUNTER_BYTES if ws is not None else 0, positions.data_ptr(), head_size, num_heads, num_kv_heads,
+        cos_sin_cache.data_ptr(), cos_sin_cache.shape[1], _dt(cos_sin_cache, True), int(is_neox), key_cache.data_ptr(),
+        value_cache.data_ptr(), slot_mapping.data_ptr(), value_cache.shape[3], key_cache.stride(0),
+        int(_is_fp8(kv_cache_dtype)), _ptr(k_scale), _ptr(v_scale), _stream()))
+    return qkv
+
+
 def w4a16_gemm_add_rms_norm(x: torch.Tensor, residual: torch.Tensor | None, norm_weight: torch.Tensor | None,
                             epsilon: float, w: PackedW4, bias: torch.Tensor | None = None, split_k: int = 0):
     """fused_add_rms_norm(x, residual) followed by the W4A16 GEMM, in one kernel.
