@@ -266,6 +266,19 @@ def test_attention_layer_prefill_then_decode(kv_dtype):
     np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-5, atol=atol)
     # memory-profiling call
     assert float(attn.impl.forward(attn, q, k, v, attn.kv_cache, None, out.clone()).abs().sum()) == 0.0
+    # the backend's fused RoPE + cache-update hook = rotary_embedding, then do_kv_cache_update
+    assert attn.impl.fused_rope_kvcache_supported()
+    pos = torch.tensor([L for L in lens], dtype=torch.int64, device=DEV)
+    inv = 1.0 / (10000.0 ** (np.arange(0, D, 2, dtype=np.float32) / D))
+    fr = np.arange(64, dtype=np.float32)[:, None] * inv[None, :]
+    cos_sin = to_dev(orc.f32_to_h16(np.concatenate([np.cos(fr), np.sin(fr)], axis=1).astype(np.float32)))
+    q1, k1, q2, k2 = q.clone(), k.clone(), q.clone(), k.clone()
+    cache1, cache2 = torch.zeros_like(attn.kv_cache), torch.zeros_like(attn.kv_cache)
+    ops.rotary_embedding(pos, q1, k1, D, cos_sin, True)
+    attn.impl.do_kv_cache_update(attn, k1, v, cache1, md.slot_mapping)
+    attn.impl.do_rope_and_kv_cache_update(attn, q2, k2, v, pos, cos_sin, True, cache2, md.slot_mapping)
+    assert torch.equal(q1, q2) and torch.equal(k1, k2) and torch.equal(cache1, cache2)
+    assert int((cache2 != 0).sum()) > 0
 
 
 def test_layer_wrappers_match_oracle():
