@@ -3,12 +3,16 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N = 1: Llama-3-8B GPTQ int4 g128, TP=1, bf16 activations, synthetic weights and prompts
-       (BASELINE.json configs[1]).  A "step" is one decode step of the whole batch.
-N > 1: Llama-3-70B GPTQ int4 g128 with TP = N (configs[3]); launched by
-       torch.distributed.run, one rank per GPU, all-reduce over RCCL.
+N = 1: Llama-3-8B GPTQ int4 g128, TP=1, bf16 activations, synthetic weights and prompts (the
+       configuration the headline metric is quoted on).  A "step" is one decode step of the whole batch.
+N > 1: Llama-3-70B GPTQ int4 g128 with TP = N; launched by torch.distributed.run, one rank per
+       GPU, all-reduce over RCCL.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md for the field definitions).
+Prints ONE JSON line on rank 0: value = output tokens per second of the whole job (inputs resident in
+HBM), ttft_ms_p50 = prompt + first token, roofline = the dominant kernel (gate_up GEMV) timed with HIP
+events on its launch stream against the 8 TB/s HBM peak, cpu_baseline = the CPU restatement of the
+reference's cpu_gemm_wna16 path timed on this host, other_shapes = the latency benchmark's other
+(batch, input_len) cases.
 """
 import argparse
 import json
