@@ -199,6 +199,11 @@ int mi355q_w4a16_mm_add_rms_norm(const void* a, int lda, const void* packed, con
                                  const void* norm_weight, float epsilon, void* out, int M, int N,
                                  int K, int G, int tile, int act_dtype, void* workspace,
                                  size_t workspace_bytes, mi355q_stream_t stream);
+/* Whether mi355q_w4a16_mm_add_rms_norm serves this shape (17+ rows on the tiled kernel, 5..16 rows
+ * when the K-sliced rows kernel is the route mi355q_w4a16_gemm would take), and the fp32 workspace
+ * it then needs. */
+int mi355q_w4a16_mm_add_rms_norm_supported(int M, int N, int K, int G, int tile, int has_zc);
+size_t mi355q_w4a16_mm_add_rms_norm_workspace_bytes(int M, int N, int K, int G, int tile, int has_zc);
 /* mi355q_w4a16_mm for the fused qkv projection of prompt tokens followed by mi355q_rope_and_cache on
  * its q / k / v column ranges (QKVParallelLinear -> rotary_emb -> cache update,
  * vllm/model_executor/models/llama.py:218-226); K-slices are merged by mi355q_splitk_rope_and_cache.

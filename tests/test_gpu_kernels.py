@@ -175,10 +175,10 @@ def test_w4a16_mm_vs_oracle(M, K, N, G, tile, awq, dt):
 
 
 @pytest.mark.parametrize("M,K,N,with_bias", [(128, 4096, 4096, False), (32, 14336, 4096, True), (600, 1024, 4096, False),
-                                              (20, 512, 8192, True)])
+                                              (20, 512, 8192, True), (8, 14336, 4096, False), (13, 14336, 4096, True)])
 def test_w4a16_mm_add_rms_norm_equals_the_two_steps(M, K, N, with_bias):
     """Projection + residual add + RMSNorm as one call: the residual is bit-identical to
-    w4a16_mm followed by fused_add_rms_norm (same slice-order sums, same roundings); the normalised rows
+    w4a16_gemm followed by fused_add_rms_norm (same slice-order sums, same roundings); the normalised rows
     may differ by one rounding where the sum of squares was added in another order.  Also against the
     oracle's GEMM + fused_add_rms_norm."""
     rng = np.random.default_rng(M + K + N)
@@ -192,7 +192,9 @@ def test_w4a16_mm_add_rms_norm_equals_the_two_steps(M, K, N, with_bias):
     qw = orc.gptq_pack(q)
     w = ops.w4a16_repack(i32(qw), to_dev(s), None, G)
     bias_d = None if bias is None else to_dev(bias)
-    c = ops.w4a16_mm(to_dev(a), w, bias=bias_d)
+    assert ops.w4a16_mm_add_rms_norm_supported(M, w)
+    # the two-step reference on the same kernel: 5..16 rows K-sliced rows kernel, 17+ tiled kernel
+    c = ops.w4a16_mm(to_dev(a), w, bias=bias_d) if M >= 17 else ops.w4a16_gemm(to_dev(a), w, bias=bias_d)
     r2 = to_dev(res).clone()
     ops.fused_add_rms_norm(c, r2, to_dev(nw), 1e-5)
     r1 = to_dev(res).clone()

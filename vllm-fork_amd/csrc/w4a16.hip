@@ -1241,6 +1241,7 @@ struct RowsParams {
   int gchunks;      // chunks per scale group
   int cps;          // chunks per K-slice = nw * CPW * bursts
   int splits, nw, bursts, rows_pp;
+  int partial_only;  // 1: leave the fp32 K-slice tiles in `partial` for a consumer kernel that sums them
 };
 
 template <typename DT, int SPB, int CPW, bool HAS_ZC>
@@ -1381,6 +1382,13 @@ __global__ __launch_bounds__(512) void w4a16_rows_kernel(const RowsParams p) {
     *reinterpret_cast<u32x2*>(p.out + (size_t)m * p.N + n) = o;
   };
 
+  if (p.partial_only) {   // the next kernel on the stream merges the slices: plain stores, no ticket
+    for (int it = threadIdx.x; it < Mt * QB; it += nthreads) {
+      const int m_l = it / QB, nl = 4 * (it % QB);
+      *reinterpret_cast<f32x4*>(p.partial + ((size_t)sp * p.M + row0 + m_l) * p.N + vstrip * BW + nl) = block_sum(m_l, nl);
+    }
+    return;
+  }
   if (p.splits == 1) {
     for (int it = threadIdx.x; it < Mt * QB; it += nthreads) {
       const int m_l = it / QB, nl = 4 * (it % QB);
@@ -1786,6 +1794,7 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
       r.partial = workspace ? (float*)((char*)workspace + COUNTER_BYTES) : nullptr;
       r.M = M; r.N = N; r.K = K; r.chunks = K / 128; r.gchunks = G / 128;
       r.splits = rp.splits; r.cps = r.chunks / rp.splits; r.nw = rp.nw; r.bursts = rp.bursts; r.rows_pp = rp.rows_pp;
+      r.partial_only = 0;
       return act_dtype == MI355Q_BF16 ? launch_rows<BF16>(r, rp.cpw, rp.lds, stream)
                                       : launch_rows<FP16>(r, rp.cpw, rp.lds, stream);
     }
@@ -2108,6 +2117,35 @@ extern "C" int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const
   return act_dtype == MI355Q_BF16 ? launch_mm<BF16>(p, mp, (hipStream_t)stream) : launch_mm<FP16>(p, mp, (hipStream_t)stream);
 }
 
+// 5..16 rows on 16-channel strips whose activations do not fit one workgroup's LDS: the K-sliced rows
+// kernel serves them (same choice as mi355q_w4a16_gemm makes)
+static bool rows_route(int M, int N, int K, int G, int tile, bool has_zc, RowsPlan* out) {
+  if (tile != 16 || M < ROWS_MIN_M || M >= 17 || getenv("MI355Q_NO_ROWS")) return false;
+  RowsPlan rp = plan_rows(M, N, K, G, has_zc);
+  if (!rp.ok) return false;
+  const BurstPlan sb = plan_burst(M, K, G, 1, has_zc);
+  if (sb.ok && sb.rows_pp >= std::min(M, 16) && (size_t)std::min(M, 16) * K * 2 <= 96 * 1024) return false;
+  *out = rp;
+  return true;
+}
+
+extern "C" int mi355q_w4a16_mm_add_rms_norm_supported(int M, int N, int K, int G, int tile, int has_zc) {
+  if (G <= 0) G = K;
+  if (M <= 0 || N <= 0 || K <= 0 || tile <= 0 || N % tile || !tile_ok(tile, K, G)) return 0;
+  RowsPlan rp;
+  if (rows_route(M, N, K, G, tile, has_zc != 0, &rp)) return 1;
+  return M >= 17 && plan_mm(M, N, K, G, tile).ok ? 1 : 0;
+}
+
+extern "C" size_t mi355q_w4a16_mm_add_rms_norm_workspace_bytes(int M, int N, int K, int G, int tile, int has_zc) {
+  if (G <= 0) G = K;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  RowsPlan rp;
+  if (rows_route(M, N, K, G, tile, has_zc != 0, &rp)) return (size_t)rp.splits * M * N * sizeof(float);
+  const MmPlan mp = plan_mm(M, N, K, G, tile);
+  return mp.ok ? mp.ws : 0;
+}
+
 /* c = a W (+ bias), then fused_add_rms_norm(c, residual): residual = round(c + residual),
  * out = round(residual * rsqrt(mean(residual^2) + eps) * norm_weight).  With K-slices the slice sums,
  * the residual add and the norm are one kernel over the fp32 partial tiles. */
@@ -2126,6 +2164,24 @@ extern "C" int mi355q_w4a16_mm_add_rms_norm(const void* a, int lda, const void* 
                      ((uintptr_t)out & 15) == 0 && ((uintptr_t)residual & 15) == 0 && ((uintptr_t)zc & 15) == 0 &&
                      ((uintptr_t)bias & 7) == 0 && ((uintptr_t)norm_weight & 15) == 0,
                  "w4a16_mm_add_rms_norm: pointers must be 16-byte aligned");
+  RowsPlan rp;
+  if (rows_route(M, N, K, G > 0 ? G : K, tile, zc != nullptr, &rp)) {
+    const size_t need = (size_t)rp.splits * M * N * sizeof(float);
+    MI355Q_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "w4a16_mm_add_rms_norm: K-slices need a 16-byte aligned workspace");
+    if (workspace_bytes < need) return set_error(MI355Q_ENOSPACE, "w4a16_mm_add_rms_norm: workspace %zu B < %zu B", workspace_bytes, need);
+    if (G <= 0) G = K;
+    RowsParams r;
+    r.x = (const uint16_t*)a; r.ldx = lda; r.wp = (const u32x4*)packed;
+    r.scales = (const uint16_t*)scales; r.zc = (const uint16_t*)zc; r.bias = nullptr;
+    r.out = (uint16_t*)out; r.counters = nullptr; r.partial = (float*)workspace;
+    r.M = M; r.N = N; r.K = K; r.chunks = K / 128; r.gchunks = G / 128;
+    r.splits = rp.splits; r.cps = r.chunks / rp.splits; r.nw = rp.nw; r.bursts = rp.bursts; r.rows_pp = rp.rows_pp;
+    r.partial_only = 1;
+    const int e = act_dtype == MI355Q_BF16 ? launch_rows<BF16>(r, rp.cpw, rp.lds, (hipStream_t)stream)
+                                           : launch_rows<FP16>(r, rp.cpw, rp.lds, (hipStream_t)stream);
+    if (e) return e;
+    return mi355q_splitk_add_rms_norm(out, residual, r.partial, rp.splits, bias, norm_weight, epsilon, M, N, act_dtype, stream);
+  }
   const MmPlan mp = plan_mm(M, N, K, G, tile);
   MI355Q_REQUIRE(mp.ok, "w4a16_mm_add_rms_norm: needs a group size that is a multiple of 128 and N a multiple of %d for strip width %d",
                  tile == 112 ? 448 : 256, tile);

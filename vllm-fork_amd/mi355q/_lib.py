@@ -47,6 +47,8 @@ _SIGS = {
     "mi355q_w4a16_gate_up_silu_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "mi355q_w4a16_mm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_vp, c_sz, c_vp]),
+    "mi355q_w4a16_mm_add_rms_norm_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mi355q_w4a16_mm_add_rms_norm_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "mi355q_w4a16_mm_add_rms_norm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_int, c_int,
                                              c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "mi355q_w4a16_mm_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),

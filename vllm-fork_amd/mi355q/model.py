@@ -215,9 +215,10 @@ class LlamaRunner:
 
     def _tail_norm_ok(self, T, lin) -> bool:
         """A row-parallel projection whose K-slice sums, residual add and the following RMSNorm can run
-        as one kernel: the tiled kernel's token range, whole projection on this rank."""
-        return (self.quant != "none" and self.tp_size == 1 and ops.MM_MIN_TOKENS <= T <= ops.MM_MAX_TOKENS
-                and ops._mm_supported(lin.w))
+        as one kernel: the token range of the tiled kernel (or of the K-sliced rows kernel), whole
+        projection on this rank."""
+        return (self.quant != "none" and self.tp_size == 1 and T <= ops.MM_MAX_TOKENS
+                and ops.w4a16_mm_add_rms_norm_supported(T, lin.w))
 
     def _layer(self, L, li, h, residual, positions, slot_mapping, attend, normed=False, next_norm=None):
         """One decoder layer.  `normed`: h already is RMSNorm(residual) (the previous layer's down

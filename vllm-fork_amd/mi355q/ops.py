@@ -197,6 +197,10 @@ def w4a16_mm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, sil
     return out
 
 
+def w4a16_mm_add_rms_norm_supported(tokens: int, w: PackedW4) -> bool:
+    return bool(_lib.lib().mi355q_w4a16_mm_add_rms_norm_supported(tokens, w.N, w.K, w.G, w.tile, int(w.zc is not None)))
+
+
 def w4a16_mm_add_rms_norm(x: torch.Tensor, w: PackedW4, residual: torch.Tensor, norm_weight: torch.Tensor,
                           epsilon: float, bias: torch.Tensor | None = None) -> torch.Tensor:
     """w4a16_mm(x, w, bias) followed by fused_add_rms_norm(result, residual): `residual` is updated in
@@ -211,8 +215,10 @@ def w4a16_mm_add_rms_norm(x: torch.Tensor, w: PackedW4, residual: torch.Tensor, 
     if residual.shape != (M, w.N) or not residual.is_contiguous() or norm_weight.numel() != w.N:
         raise RuntimeError(f"w4a16_mm_add_rms_norm: residual must be contiguous [{M}, {w.N}] and the norm weight [{w.N}]")
     L = _lib.lib()
+    if not L.mi355q_w4a16_mm_add_rms_norm_supported(M, w.N, w.K, w.G, w.tile, int(w.zc is not None)):
+        raise RuntimeError(f"w4a16_mm_add_rms_norm: {M} rows of a [{w.K}, {w.N}] projection (strip {w.tile}) are not served")
     out = torch.empty((M, w.N), dtype=x.dtype, device=x.device)
-    need = L.mi355q_w4a16_mm_workspace_bytes(M, w.N, w.K, w.G, w.tile)
+    need = L.mi355q_w4a16_mm_add_rms_norm_workspace_bytes(M, w.N, w.K, w.G, w.tile, int(w.zc is not None))
     ws = _workspace(x.device, need + COUNTER_BYTES) if need else None
     check(L.mi355q_w4a16_mm_add_rms_norm(
         x.data_ptr(), x.stride(0), w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc), _ptr(bias), residual.data_ptr(),
