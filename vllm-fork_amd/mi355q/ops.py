@@ -7,6 +7,8 @@ stream and never synchronises; outputs come from torch's caching allocator, so
 the ops are HIP-graph capturable.  All arithmetic runs in libmi355q.so; there is
 no eager/CPU fallback.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -104,7 +106,7 @@ DEQUANT_MATMUL_MIN_TOKENS = 32
 # token range served by the tiled matrix-core W4A16 kernel (below: the decode kernels; above: dequantise
 # once + dense GEMM, compute-bound and best left to the BLAS)
 MM_MIN_TOKENS = 17
-MM_MAX_TOKENS = 768
+MM_MAX_TOKENS = int(os.environ.get("MI355Q_MM_MAX_TOKENS", "768"))
 
 
 COUNTER_BYTES = 64 * 1024   # arrival counters at the head of the workspace; partial tiles follow
