@@ -357,6 +357,11 @@ int mi355q_rotary_embedding(const int64_t* positions, void* query, int64_t query
 /* out[T,d] = silu(x[T,:d]) * x[T,d:].  Replaces torch.ops._C.silu_and_mul. */
 int mi355q_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dtype,
                         mi355q_stream_t stream);
+/* The same on a pair-interleaved row [T, 2 d] = (gate_0, up_0, gate_1, up_1, ...), the channel order a
+ * gate_up weight repacked with MI355Q_W_PAIR_HALVES produces: out[t, i] = silu(in[t, 2 i]) * in[t, 2 i + 1].
+ * d a multiple of 8. */
+int mi355q_silu_and_mul_pairs(void* out, const void* input, int num_tokens, int d, int dtype,
+                              mi355q_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* KV cache + paged attention (ROCM_ATTN layout)                       */

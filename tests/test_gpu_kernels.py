@@ -458,6 +458,16 @@ def test_rope_golden(golden):
         np.testing.assert_allclose(f32(to_bits(q)), f32(g[tag + "_qo"]), rtol=1.6e-2, atol=2e-2)
 
 
+def test_silu_and_mul_pairs_equals_silu_and_mul_of_the_separated_halves():
+    x = (torch.randn(5, 2 * 1024, device=DEV) * 3).to(torch.bfloat16)
+    ref = torch.empty((5, 1024), dtype=torch.bfloat16, device=DEV)
+    ops.silu_and_mul(ref, ops.unpair_halves(x).contiguous())
+    out = torch.empty_like(ref)
+    ops.silu_and_mul_pairs(out, x)
+    assert torch.equal(out, ref)
+    assert np.array_equal(to_bits(out), orc.silu_and_mul(to_bits(ops.unpair_halves(x).contiguous())))
+
+
 def test_silu_and_mul():
     x = torch.randn(7, 2 * 1000, device=DEV).to(torch.bfloat16) * 3
     out = torch.empty((7, 1000), dtype=torch.bfloat16, device=DEV)

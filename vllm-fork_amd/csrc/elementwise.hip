@@ -285,6 +285,29 @@ __global__ void silu_mul_kernel(uint16_t* __restrict__ out, const uint16_t* __re
   }
 }
 
+// SiLU-and-multiply over a pair-interleaved row (g0, u0, g1, u1, ...): out[i] = silu(x[2 i]) * x[2 i + 1].
+// What silu_mul_kernel gives after the halves have been separated; eight pairs per thread and step.
+template <typename DT>
+__global__ __launch_bounds__(256) void silu_mul_pairs_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ in,
+                                                             int d) {
+  const u32x4* x = reinterpret_cast<const u32x4*>(in + (size_t)blockIdx.x * 2 * d);
+  u32x4* y = reinterpret_cast<u32x4*>(out + (size_t)blockIdx.x * d);
+  for (int v = threadIdx.x; v < d / 8; v += 256) {
+    const u32x4 a = x[2 * v], b = x[2 * v + 1];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t p0 = e < 2 ? a[2 * e] : b[2 * e - 4], p1 = e < 2 ? a[2 * e + 1] : b[2 * e - 3];
+      const float g0 = DT::to_f32((uint16_t)(p0 & 0xffff)), u0 = DT::to_f32((uint16_t)(p0 >> 16));
+      const float g1 = DT::to_f32((uint16_t)(p1 & 0xffff)), u1 = DT::to_f32((uint16_t)(p1 >> 16));
+      const float s0 = DT::to_f32(DT::from_f32(g0 / (1.0f + __expf(-g0))));
+      const float s1 = DT::to_f32(DT::from_f32(g1 / (1.0f + __expf(-g1))));
+      o[e] = (uint32_t)DT::from_f32(s0 * u0) | ((uint32_t)DT::from_f32(s1 * u1) << 16);
+    }
+    y[v] = o;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // KV-cache write
 // ---------------------------------------------------------------------------
@@ -774,6 +797,17 @@ extern "C" int mi355q_silu_and_mul(void* out, const void* input, int num_tokens,
   DISPATCH_H16(dtype, hipLaunchKernelGGL((silu_mul_kernel<DT>), dim3(num_tokens), dim3(d < 1024 ? (d + 63) / 64 * 64 : 1024),
                                          0, (hipStream_t)stream, (uint16_t*)out, (const uint16_t*)input, d));
   return check_launch("silu_mul_kernel");
+}
+
+extern "C" int mi355q_silu_and_mul_pairs(void* out, const void* input, int num_tokens, int d, int dtype,
+                                         mi355q_stream_t stream) {
+  if (int e = check_h16(dtype, "silu_and_mul_pairs")) return e;
+  if (num_tokens == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(out && input && d > 0 && d % 8 == 0, "silu_and_mul_pairs: d = %d must be a positive multiple of 8", d);
+  MI355Q_REQUIRE((((uintptr_t)out | (uintptr_t)input) & 15) == 0, "silu_and_mul_pairs: tensors must be 16-byte aligned");
+  DISPATCH_H16(dtype, hipLaunchKernelGGL((silu_mul_pairs_kernel<DT>), dim3(num_tokens), dim3(256), 0, (hipStream_t)stream,
+                                         (uint16_t*)out, (const uint16_t*)input, d));
+  return check_launch("silu_mul_pairs_kernel");
 }
 
 extern "C" int mi355q_reshape_and_cache(const void* key, const void* value, int64_t key_stride,

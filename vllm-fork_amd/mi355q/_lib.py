@@ -68,6 +68,7 @@ _SIGS = {
     "mi355q_rotary_embedding": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_int,
                                         c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_silu_and_mul": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "mi355q_silu_and_mul_pairs": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "mi355q_reshape_and_cache": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int,
                                          c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     "mi355q_rope_and_cache": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_int,

@@ -298,6 +298,12 @@ class LlamaRunner:
         else:
             if not o_normed:
                 ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
+            if self.quant != "none" and L["gate_up"].w.pair_halves:
+                # long prompts (dequantise + dense GEMM): SiluAndMul straight on the pair-interleaved output
+                raw = ops.w4a16_gemm(o, L["gate_up"].w)
+                act = torch.empty((T, raw.shape[1] // 2), dtype=raw.dtype, device=raw.device)
+                ops.silu_and_mul_pairs(act, raw)
+                return down(act)
             gu = L["gate_up"](o)
         if tail:   # the fused tail takes the activation itself
             act = torch.empty((T, gu.shape[1] // 2), dtype=gu.dtype, device=gu.device)

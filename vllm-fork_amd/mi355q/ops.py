@@ -637,6 +637,18 @@ def silu_and_mul(out: torch.Tensor, input: torch.Tensor) -> None:
                                          _dt(input), _stream()))
 
 
+def silu_and_mul_pairs(out: torch.Tensor, input: torch.Tensor) -> None:
+    """silu_and_mul on the pair-interleaved output (g0, u0, g1, u1, ...) of a gate_up projection repacked
+    with pair_halves: out[..., i] = silu(input[..., 2 i]) * input[..., 2 i + 1] -- silu_and_mul(out,
+    unpair_halves(input)) without the copy."""
+    _need_cuda(out, input)
+    d = input.shape[-1] // 2
+    if not input.is_contiguous() or not out.is_contiguous() or out.shape[-1] != d:
+        raise RuntimeError("silu_and_mul_pairs: tensors must be contiguous, out [.., d] for input [.., 2 d]")
+    check(_lib.lib().mi355q_silu_and_mul_pairs(out.data_ptr(), input.data_ptr(), input.numel() // (2 * d), d,
+                                               _dt(input), _stream()))
+
+
 # ---------------------------------------------------------------------------
 # KV cache + attention
 # ---------------------------------------------------------------------------
