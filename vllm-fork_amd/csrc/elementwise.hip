@@ -398,6 +398,73 @@ __global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uin
   }
 }
 
+// NeoX pairing over the whole head, head a multiple of 16: four pairs per work item, 8-byte accesses.
+template <typename DT, bool FP8>
+__global__ __launch_bounds__(1024) void rope_and_cache_vec_kernel(
+    const int64_t* __restrict__ positions, uint16_t* __restrict__ q, int64_t q_stride, uint16_t* __restrict__ k,
+    int64_t k_stride, const uint16_t* __restrict__ v, int64_t v_stride, int head, int nh, int nkv,
+    const void* __restrict__ cache, int cache_dtype, void* __restrict__ kc, void* __restrict__ vc,
+    const int64_t* __restrict__ slot_mapping, int bs, int64_t block_stride, const float* __restrict__ k_scale,
+    const float* __restrict__ v_scale) {
+  const int t = blockIdx.x;
+  const int e = head / 2, q4 = e / 4;
+  const size_t cbase = (size_t)positions[t] * head;
+  const int64_t slot = slot_mapping[t];
+  const int64_t b = slot / bs, o = slot % bs;
+  constexpr int X = FP8 ? 16 : 8;
+  const float ks = FP8 ? *k_scale : 1.f, vs = FP8 ? *v_scale : 1.f;
+  auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
+  auto hi = [](uint32_t u) { return DT::to_f32((uint16_t)(u >> 16)); };
+  const int rope_items = (nh + nkv) * q4, v_items = nkv * head / 4;
+  for (int item = threadIdx.x; item < rope_items + v_items; item += blockDim.x) {
+    if (item < rope_items) {
+      const int h = item / q4, i4 = (item - h * q4) * 4;
+      const bool is_k = h >= nh;
+      uint16_t* arr = is_k ? k + (size_t)t * k_stride + (size_t)(h - nh) * head : q + (size_t)t * q_stride + (size_t)h * head;
+      const u32x2 xv = *reinterpret_cast<const u32x2*>(arr + i4), yv = *reinterpret_cast<const u32x2*>(arr + e + i4);
+      const float x[4] = {lo(xv[0]), hi(xv[0]), lo(xv[1]), hi(xv[1])}, y[4] = {lo(yv[0]), hi(yv[0]), lo(yv[1]), hi(yv[1])};
+      uint16_t xo[4], yo[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float c = load_cache(cache, cbase + i4 + j, cache_dtype);
+        const float s = load_cache(cache, cbase + e + i4 + j, cache_dtype);
+        xo[j] = DT::from_f32(x[j] * c - y[j] * s);
+        yo[j] = DT::from_f32(y[j] * c + x[j] * s);
+      }
+      *reinterpret_cast<u32x2*>(arr + i4) = u32x2{(uint32_t)xo[0] | ((uint32_t)xo[1] << 16), (uint32_t)xo[2] | ((uint32_t)xo[3] << 16)};
+      *reinterpret_cast<u32x2*>(arr + e + i4) = u32x2{(uint32_t)yo[0] | ((uint32_t)yo[1] << 16), (uint32_t)yo[2] | ((uint32_t)yo[3] << 16)};
+      if (is_k && slot >= 0) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+          const int d = half ? e + i4 : i4;
+          const uint16_t* bits = half ? yo : xo;
+          const size_t ki = (size_t)b * block_stride + (((size_t)(h - nh) * (head / X) + d / X) * bs + o) * X + d % X;
+          if constexpr (FP8) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) w |= (uint32_t)f32_to_fp8(DT::to_f32(bits[j]) / ks) << (8 * j);
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(kc) + ki) = w;
+          } else {
+            *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(kc) + ki) =
+                u32x2{(uint32_t)bits[0] | ((uint32_t)bits[1] << 16), (uint32_t)bits[2] | ((uint32_t)bits[3] << 16)};
+          }
+        }
+      }
+    } else if (slot >= 0) {
+      const int j4 = (item - rope_items) * 4;
+      const int h = j4 / head, d = j4 - h * head;
+      const u32x2 vv = *reinterpret_cast<const u32x2*>(v + (size_t)t * v_stride + j4);
+      const uint16_t vb[4] = {(uint16_t)(vv[0] & 0xffff), (uint16_t)(vv[0] >> 16), (uint16_t)(vv[1] & 0xffff), (uint16_t)(vv[1] >> 16)};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const size_t vi = (size_t)b * block_stride + ((size_t)h * head + d + j) * bs + o;
+        if constexpr (FP8) reinterpret_cast<uint8_t*>(vc)[vi] = f32_to_fp8(DT::to_f32(vb[j]) / vs);
+        else reinterpret_cast<uint16_t*>(vc)[vi] = vb[j];
+      }
+    }
+  }
+}
+
 // The fused qkv projection finished in one pass over the token: K-slice sums of the fp32 partial tiles
 // (slice order, rounded to the activation dtype, bias added to the rounded value), NeoX RoPE over the
 // whole head on q and k, the rotated row written to `qkv` and k, v to the paged cache.  Equal, bit for
@@ -857,9 +924,25 @@ extern "C" int mi355q_rope_and_cache(const int64_t* positions, void* query, int6
   MI355Q_REQUIRE(head_size % (kv_fp8 ? 16 : 8) == 0, "rope_and_cache: head_size %d", head_size);
   MI355Q_REQUIRE(num_heads > 0 && num_kv_heads > 0 && block_size > 0, "rope_and_cache: bad sizes");
   if (kv_fp8) MI355Q_REQUIRE(k_scale && v_scale, "rope_and_cache: fp8 cache needs k_scale/v_scale");
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = is_neox && rot_dim == head_size && head_size % 16 == 0 && query_stride % 4 == 0 && key_stride % 4 == 0 &&
+                   value_stride % 4 == 0 && (((uintptr_t)query | (uintptr_t)key | (uintptr_t)value | (uintptr_t)key_cache) & 7) == 0 &&
+                   !getenv("MI355Q_ROPE_SCALAR");
+  if (vec) {
+    const int items = (num_heads + num_kv_heads) * head_size / 8 + num_kv_heads * head_size / 4;
+    const int vthreads = items >= 1024 ? 1024 : (items + 63) / 64 * 64;
+#define MI355Q_RCV(F8)                                                                                              \
+  DISPATCH_H16(dtype, hipLaunchKernelGGL((rope_and_cache_vec_kernel<DT, F8>), dim3(num_tokens), dim3(vthreads), 0, s, \
+                                         positions, (uint16_t*)query, query_stride, (uint16_t*)key, key_stride,        \
+                                         (const uint16_t*)value, value_stride, head_size, num_heads, num_kv_heads,    \
+                                         cos_sin_cache, cache_dtype, key_cache, value_cache, slot_mapping, block_size, \
+                                         block_stride, k_scale, v_scale))
+    if (kv_fp8) { MI355Q_RCV(true); } else { MI355Q_RCV(false); }
+#undef MI355Q_RCV
+    return check_launch("rope_and_cache_vec_kernel");
+  }
   int threads = (num_heads + num_kv_heads) * rot_dim / 2;
   threads = threads < 64 ? 64 : (threads > 1024 ? 1024 : (threads + 63) / 64 * 64);
-  hipStream_t s = (hipStream_t)stream;
 #define MI355Q_RC(F8)                                                                                            \
   DISPATCH_H16(dtype, hipLaunchKernelGGL((rope_and_cache_kernel<DT, F8>), dim3(num_tokens), dim3(threads), 0, s,   \
                                          positions, (uint16_t*)query, query_stride, (uint16_t*)key, key_stride,     \
