@@ -1539,8 +1539,9 @@ __device__ inline void mm_store(const MmParams& p, int row, int n, f32x4 a) {
   }
 }
 
+// (32-row tiles are held to 256 registers; measured + 1 % on decode batches of 24 / 32)
 template <typename DT, int NS, int SPW, int RT, bool HAS_ZC>
-__global__ __launch_bounds__(256) void w4a16_mm_kernel(const MmParams p) {
+__global__ __launch_bounds__(256, RT == 2 ? 2 : 1) void w4a16_mm_kernel(const MmParams p) {
   constexpr int CT = NS * SPW, SW = 16 * NS, QW = 4 * NS, BM = 16 * RT;
   constexpr int ASTR = 128 + 16;  // LDS row stride (elements): 32 bytes of padding keep ds_read_b128 conflict-free
   __shared__ __attribute__((aligned(16))) uint16_t abuf[2][BM * ASTR];
