@@ -479,7 +479,9 @@ def test_act_order_row_permutation_helpers():
     K, N, G = 256, 16, 64
     assert _act_order_perm(None, K, G) is None
     assert _act_order_perm(torch.empty(0, dtype=torch.int32), K, G) is None
-    assert _act_order_perm(torch.zeros(K, dtype=torch.int32), K, G) is None          # untouched placeholder
+    with pytest.raises(ValueError, match="exactly group_size rows"):                  # a g_idx that was never loaded
+        _act_order_perm(torch.zeros(K, dtype=torch.int32), K, G)
+    assert _act_order_perm(torch.zeros(K, dtype=torch.int32), K, K) is None          # one group: all zeros is right
     assert _act_order_perm(torch.arange(K, dtype=torch.int32) // G, K, G) is None     # already in group order
     g_idx = rng.permutation(np.arange(K) // G).astype(np.int32)
     perm = _act_order_perm(torch.from_numpy(g_idx), K, G)
@@ -494,3 +496,47 @@ def test_act_order_row_permutation_helpers():
     q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
     got = _permute_packed_rows(torch.from_numpy(orc.gptq_pack(q)), perm)
     assert np.array_equal(got.numpy(), orc.gptq_pack(q[perm.numpy()]))
+
+
+# ---------------------------------------------------------------------------
+# quantized output head (`lm_head: true` checkpoints)
+# ---------------------------------------------------------------------------
+def test_quantized_lm_head_gets_a_gptq_method_and_vocab_shards(tp):
+    """gptq_utils.py:140-156: a ParallelLMHead takes the quantized linear method when the config says
+    lm_head, the unquantized embedding method when it is excluded by a dynamic rule, and nothing
+    special otherwise; its packed tensors are sharded along the vocabulary."""
+    from mi355q.plugin.gptq import AutoGPTQLinearMethod
+    from mi355q.plugin.linear import ParallelLMHead, UnquantizedEmbeddingMethod
+    V, H, G = 1024, 256, 128
+    rng = np.random.default_rng(7)
+    q, s, _ = _gptq_tensors(rng, H, V, G)
+    qw = _t(orc.gptq_pack(q))
+    for size in (1, 2):
+        for rank in range(size):
+            tp(rank, size)
+            c = AutoGPTQConfig.from_config(dict(GPTQ_CFG, lm_head=True))
+            head = ParallelLMHead(V, H, params_dtype=torch.bfloat16, quant_config=c, prefix="lm_head")
+            assert isinstance(head.quant_method, AutoGPTQLinearMethod)
+            n = V // size
+            assert head.qweight.shape == (H // 8, n) and head.scales.shape == (H // G, n)
+            head.weight_loader(head.qweight, qw)
+            head.weight_loader(head.scales, _bf(s))
+            assert torch.equal(head.qweight.data, qw[:, rank * n:(rank + 1) * n])
+            assert torch.equal(head.scales.data, _bf(s)[:, rank * n:(rank + 1) * n])
+    tp(0, 1)
+    plain = ParallelLMHead(V, H, params_dtype=torch.bfloat16, quant_config=AutoGPTQConfig.from_config(GPTQ_CFG),
+                           prefix="lm_head")
+    assert isinstance(plain.quant_method, UnquantizedEmbeddingMethod) and plain.weight.shape == (V, H)
+    excluded = AutoGPTQConfig.from_config(dict(GPTQ_CFG, lm_head=True, dynamic={"-:lm_head": {}}))
+    head = ParallelLMHead(V, H, params_dtype=torch.bfloat16, quant_config=excluded, prefix="lm_head")
+    assert isinstance(head.quant_method, UnquantizedEmbeddingMethod)
+    awq = AutoAWQConfig.from_config(dict(AWQ_CFG, lm_head=True))
+    assert awq.get_quant_method(ParallelLMHead(V, H, params_dtype=torch.bfloat16), "lm_head") is not None
+    assert AutoAWQConfig.from_config(AWQ_CFG).get_quant_method(ParallelLMHead(V, H, params_dtype=torch.bfloat16), "lm_head") is None
+    # vocabulary padded to 64 * tp rows; the last rank's padding rows are zero
+    tp(1, 2)
+    odd = ParallelLMHead(1000, H, params_dtype=torch.bfloat16)
+    assert odd.num_embeddings_padded == 1024 and odd.weight.shape == (512, H)
+    w = torch.randn(1000, H).to(torch.bfloat16)
+    odd.weight_loader(odd.weight, w)
+    assert torch.equal(odd.weight.data[:488], w[512:]) and not odd.weight.data[488:].any()

@@ -6,8 +6,9 @@ impl.forward :367-469, impl.do_kv_cache_update :471-517; the split of the cache 
 K [blocks, kv_heads, head/x, block, x] and V [blocks, kv_heads, head, block] views follows
 vllm/v1/attention/ops/paged_attn.py:16-29, and the prefill-rows / decode-rows split follows
 vllm/v1/attention/ops/chunked_prefill_paged_decode.py:271-493.  Unlike the reference nothing
-is allocated per call: the partition scratch is owned by the impl and grown outside graph
-capture.
+is allocated per call: the partition scratch is one buffer per device, shared by the impls of all
+layers (their launches are ordered on one stream), reserved up front by the metadata builder and only
+ever grown outside graph capture.
 """
 from dataclasses import dataclass
 
@@ -62,6 +63,49 @@ class Mi355AttentionMetadataBuilder:
         md = self.build(0, common_attn_metadata)
         md.seq_lens.fill_(1)   # capture with the shortest context; replay reads the live values
         return md
+
+
+# (device, dtype) -> (tmp_out [rows, heads, P, head], exp_sums [rows, heads, P], max_logits [same]) as flat buffers.
+# One per device for every attention layer: a layer's launch has consumed its partials before the next
+# layer's launch starts (one stream), so the layers can share them.
+_SCRATCH: dict = {}
+_SCRATCH_RETIRED: list = []   # captured graphs may still hold the address of an outgrown buffer
+# Upper bound of what reserve_partition_scratch takes up front (bytes of tmp_out); longer batches grow it
+# at their first eager run instead.
+SCRATCH_RESERVE_LIMIT = int(__import__("os").environ.get("MI355Q_ATTN_SCRATCH_LIMIT", str(1 << 30)))
+
+
+def _scratch_views(rows: int, heads: int, parts: int, head_size: int, dtype, device):
+    device = torch.device(device)
+    if device.index is None and device.type == "cuda":
+        device = torch.device("cuda", torch.cuda.current_device())
+    need = rows * heads * parts
+    key = (device, dtype)
+    s = _SCRATCH.get(key)
+    if s is None or s[0].numel() < need * head_size or s[1].numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("attention scratch must be sized before graph capture (reserve_partition_scratch, "
+                               "or run one eager step)")
+        if s is not None:
+            _SCRATCH_RETIRED.append(s)
+        s = (torch.empty(need * head_size, dtype=dtype, device=device),
+             torch.empty(need, dtype=torch.float32, device=device),
+             torch.empty(need, dtype=torch.float32, device=device))
+        _SCRATCH[key] = s
+    return (s[0][:need * head_size].view(rows, heads, parts, head_size), s[1][:need].view(rows, heads, parts),
+            s[2][:need].view(rows, heads, parts))
+
+
+def reserve_partition_scratch(max_tokens: int, max_seq_len: int, num_heads: int, head_size: int, dtype,
+                              device) -> int:
+    """Size the shared partition scratch for batches of up to `max_tokens` query rows over contexts of up
+    to `max_seq_len` tokens, capped at SCRATCH_RESERVE_LIMIT bytes; returns the rows reserved.  Called by
+    the metadata builder before the memory-profiling run, so the KV-cache sizing sees the allocation."""
+    parts = (max_seq_len + _lib.PA_PARTITION - 1) // _lib.PA_PARTITION
+    per_row = num_heads * parts * head_size * torch.empty((), dtype=dtype).element_size()
+    rows = max(1, min(max_tokens, SCRATCH_RESERVE_LIMIT // max(per_row, 1)))
+    _scratch_views(rows, num_heads, parts, head_size, dtype, device)
+    return rows
 
 
 class Mi355AttentionBackend:
@@ -135,19 +179,11 @@ class Mi355AttentionImpl:
         self.alibi_slopes = None if alibi_slopes is None else torch.tensor(alibi_slopes, dtype=torch.float32)
         self.kv_cache_dtype = kv_cache_dtype
         self.num_queries_per_kv = num_heads // num_kv_heads
-        self._scratch = None
 
     # -- scratch -----------------------------------------------------------
     def _partition_scratch(self, rows: int, max_seq_len: int, dtype, device):
         P = (max_seq_len + _lib.PA_PARTITION - 1) // _lib.PA_PARTITION
-        s = self._scratch
-        if s is None or s[0].shape[0] < rows or s[0].shape[2] < P or s[0].dtype != dtype or s[0].device != device:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("attention scratch must be sized before graph capture (run one eager step)")
-            tmp = torch.empty((rows, self.num_heads, P, self.head_size), dtype=dtype, device=device)
-            es = torch.empty((rows, self.num_heads, P), dtype=torch.float32, device=device)
-            self._scratch = s = (tmp, es, torch.empty_like(es))
-        return s
+        return _scratch_views(rows, self.num_heads, P, self.head_size, dtype, device)
 
     def _caches(self, kv_cache):
         k, v = split_kv_cache(kv_cache, self.num_kv_heads, self.head_size)
@@ -177,6 +213,12 @@ class Mi355AttentionImpl:
         o = output[:T].view(T, self.num_heads, self.head_size)
         k, v = self._caches(kv_cache)
         bs = v.shape[3]
+        P = (md.max_seq_len + _lib.PA_PARTITION - 1) // _lib.PA_PARTITION
+        per_row = self.num_heads * P * self.head_size * q.element_size()
+        cap = max(16, SCRATCH_RESERVE_LIMIT // per_row)
+        if md.max_query_len > 1 and P > 1 and T > cap and not torch.cuda.is_current_stream_capturing():
+            self._prefill_in_row_chunks(layer, q, o, k, v, bs, md, cap)
+            return output
         tmp, es, ml = self._partition_scratch(T, md.max_seq_len, q.dtype, q.device)
         if md.max_query_len > 1:
             ops.paged_prefill_attention(o, es, ml, tmp, q, k, v, self.num_kv_heads, self.scale, md.block_table,
@@ -187,6 +229,36 @@ class Mi355AttentionImpl:
                                      md.seq_lens, md.query_start_loc, bs, md.max_seq_len, self.alibi_slopes,
                                      self.kv_cache_dtype, layer._k_scale, layer._v_scale)
         return output
+
+    def _prefill_in_row_chunks(self, layer, q, o, k, v, bs, md, cap: int) -> None:
+        """Long prompts over long contexts: the per-row partition scratch is kept to `cap` query rows by
+        running the batch as consecutive row ranges.  Rows [a, b) of a sequence with query rows
+        [qs, qe) and context length L form a sequence of their own with query length rb - ra and
+        context length L - (qe - rb): row j then attends [0, L - (qe - qs) + (ra - qs) + j], as before."""
+        qsl = md.query_start_loc.cpu().tolist()
+        lens = md.seq_lens.cpu().tolist()
+        T = md.num_actual_tokens
+        for a in range(0, T, cap):
+            b = min(T, a + cap)
+            idx, new_qsl, new_lens = [], [0], []
+            for s_i, L in enumerate(lens):
+                qs, qe = qsl[s_i], qsl[s_i + 1]
+                ra, rb = max(a, qs), min(b, qe)
+                if ra >= rb:
+                    continue
+                idx.append(s_i)
+                new_qsl.append(new_qsl[-1] + rb - ra)
+                new_lens.append(L - (qe - rb))
+            dev = q.device
+            sel = torch.tensor(idx, dtype=torch.long, device=dev)
+            c_qsl = torch.tensor(new_qsl, dtype=torch.int32, device=dev)
+            c_lens = torch.tensor(new_lens, dtype=torch.int32, device=dev)
+            c_maxq = max(new_qsl[i + 1] - new_qsl[i] for i in range(len(idx)))
+            c_maxl = max(new_lens)
+            tmp, es, ml = self._partition_scratch(b - a, c_maxl, q.dtype, dev)
+            ops.paged_prefill_attention(o[a:b], es, ml, tmp, q[a:b], k, v, self.num_kv_heads, self.scale,
+                                        md.block_table.index_select(0, sel).contiguous(), c_lens, c_qsl, c_maxq, bs,
+                                        c_maxl, self.alibi_slopes, self.kv_cache_dtype, layer._k_scale, layer._v_scale)
 
     def fused_rope_kvcache_supported(self) -> bool:
         return True

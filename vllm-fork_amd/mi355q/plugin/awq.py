@@ -12,7 +12,7 @@ from typing import Any
 import torch
 
 from .. import _lib
-from .linear import LinearBase, LinearMethodBase, UnquantizedLinearMethod
+from .linear import LinearBase, LinearMethodBase, ParallelLMHead, UnquantizedLinearMethod
 from .mp_kernel import MI355XW4A16LinearKernel, MPLinearLayerConfig, choose_mp_linear_kernel
 from .parameter import GroupQuantScaleParameter, PackedvLLMParameter
 from .registry import QuantizationConfig, register_quantization_config
@@ -88,8 +88,8 @@ class AutoAWQConfig(QuantizationConfig):
         return None
 
     def get_quant_method(self, layer: torch.nn.Module, prefix: str):
-        if not isinstance(layer, LinearBase):
-            return None
+        if not (isinstance(layer, LinearBase) or (isinstance(layer, ParallelLMHead) and self.lm_head_quantized)):
+            return None     # auto_awq.py:288-290
         if is_layer_skipped(prefix, self.modules_to_not_convert, self.packed_modules_mapping):
             return UnquantizedLinearMethod()
         return AutoAWQLinearMethod(self)

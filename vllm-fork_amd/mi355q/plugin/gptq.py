@@ -11,7 +11,8 @@ from typing import Any
 import torch
 
 from .. import _lib
-from .linear import LinearBase, LinearMethodBase, UnquantizedLinearMethod
+from .linear import (LinearBase, LinearMethodBase, ParallelLMHead, UnquantizedEmbeddingMethod,
+                     UnquantizedLinearMethod)
 from .mp_kernel import MPLinearLayerConfig, choose_mp_linear_kernel
 from .parameter import (ChannelQuantScaleParameter, GroupQuantScaleParameter, PackedColumnParameter,
                         PackedvLLMParameter, RowvLLMParameter)
@@ -70,13 +71,14 @@ def is_layer_gptq_quantized(prefix: str, quantized_layers: list, fused_mapping: 
 def get_linear_quant_method(config: "AutoGPTQConfig", layer: torch.nn.Module, prefix: str, linear_method_cls: type):
     """Per-layer method: unquantized when excluded, otherwise `linear_method_cls` on a private
     copy of the config with this module's overrides applied (gptq_utils.py:133-163)."""
-    if not isinstance(layer, LinearBase):
-        return None
     cfg = copy.deepcopy(config)
+    lm_head = isinstance(layer, ParallelLMHead) and cfg.lm_head_quantized
+    if not (isinstance(layer, LinearBase) or lm_head):
+        return None
     listed = (not cfg.modules_in_block_to_quantize or
               is_layer_gptq_quantized(prefix, cfg.modules_in_block_to_quantize, cfg.packed_modules_mapping))
     if get_dynamic_override(cfg, prefix) is False or not listed:
-        return UnquantizedLinearMethod()
+        return UnquantizedEmbeddingMethod() if lm_head else UnquantizedLinearMethod()
     if prefix:
         override_config(cfg, prefix)
     return linear_method_cls(cfg)

@@ -3,7 +3,8 @@
 Mirrors the caller side of the hot path, vllm/model_executor/layers/linear.py: LinearMethodBase
 :133-181, UnquantizedLinearMethod :184-230, LinearBase :233-310, ColumnParallelLinear :419-616,
 MergedColumnParallelLinear :661-1020, QKVParallelLinear :1022-1426, RowParallelLinear
-:1613-1782.  Only the v2 weight-loading protocol is provided (every method on this path is in
+:1613-1782, and of the output embedding, vocab_parallel_embedding.py: UnquantizedEmbeddingMethod :35-84,
+ParallelLMHead :521-583 with the vocabulary-sharded loader :445-485.  Only the v2 weight-loading protocol is provided (every method on this path is in
 WEIGHT_LOADER_V2_SUPPORTED, :49-66): checkpoint tensors arrive through
 `layer.weight_loader(param, tensor[, shard_id])` and the parameter object narrows its own
 tensor-parallel shard.
@@ -254,3 +255,94 @@ class RowParallelLinear(LinearBase):
         if self.reduce_results and self.tp_size > 1:
             out = tensor_model_parallel_all_reduce(out)
         return self._ret(out, bias)
+
+
+DEFAULT_VOCAB_PADDING_SIZE = 64
+
+
+def pad_vocab_size(vocab_size: int, pad_to: int = DEFAULT_VOCAB_PADDING_SIZE) -> int:
+    return ((vocab_size + pad_to - 1) // pad_to) * pad_to
+
+
+class UnquantizedEmbeddingMethod(QuantizeMethodBase):
+    """16-bit [vocab / tp, hidden] weight of an embedding / output head (vocab_parallel_embedding.py:35-84)."""
+
+    def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
+                       params_dtype, **extra_weight_attrs):
+        w = ModelWeightParameter(data=torch.zeros(sum(output_partition_sizes), input_size_per_partition,
+                                                  dtype=params_dtype),
+                                 input_dim=1, output_dim=0, weight_loader=extra_weight_attrs.get("weight_loader"))
+        layer.register_parameter("weight", w)
+
+    def apply(self, layer, x, bias=None):
+        return UnquantizedLinearMethod.apply(self, layer, x, bias)
+
+    SKINNY_MAX_TOKENS = UnquantizedLinearMethod.SKINNY_MAX_TOKENS
+
+    def embedding(self, layer, input_):
+        return torch.nn.functional.embedding(input_, layer.weight)
+
+
+class ParallelLMHead(nn.Module):
+    """Output embedding split over ranks along the vocabulary (padded to a multiple of 64 so that every
+    rank holds the same number of rows).  Its weights are used by the logits computation through
+    `quant_method.apply(lm_head, hidden)`; a quantization config that says `lm_head: true` gives it a
+    quantized linear method, whose packed tensors are sharded along their output dimension with the
+    packing factor taken into account (vocab_parallel_embedding.py:445-485)."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, bias: bool = False, params_dtype=None,
+                 org_num_embeddings: int | None = None, padding_size: int = DEFAULT_VOCAB_PADDING_SIZE,
+                 quant_config: QuantizationConfig | None = None, prefix: str = ""):
+        super().__init__()
+        self.tp_rank, self.tp_size = get_tensor_model_parallel_rank(), get_tensor_model_parallel_world_size()
+        self.num_embeddings, self.embedding_dim, self.prefix = num_embeddings, embedding_dim, prefix
+        self.org_vocab_size = org_num_embeddings or num_embeddings
+        if self.org_vocab_size != num_embeddings:
+            raise NotImplementedError("added (LoRA) vocabulary is not supported")
+        self.num_embeddings_padded = pad_vocab_size(num_embeddings, padding_size * self.tp_size)
+        self.num_embeddings_per_partition = self.num_embeddings_padded // self.tp_size
+        self.vocab_start = min(self.tp_rank * self.num_embeddings_per_partition, self.org_vocab_size)
+        self.vocab_end = min(self.vocab_start + self.num_embeddings_per_partition, self.org_vocab_size)
+        self.params_dtype = params_dtype or torch.get_default_dtype()
+        method = quant_config.get_quant_method(self, prefix=prefix) if quant_config is not None else None
+        self.quant_method: QuantizeMethodBase = method or UnquantizedEmbeddingMethod()
+        self.quant_method.create_weights(self, embedding_dim, [self.num_embeddings_per_partition], embedding_dim,
+                                         self.num_embeddings_padded, params_dtype=self.params_dtype,
+                                         weight_loader=self.weight_loader)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(self.num_embeddings_per_partition, dtype=self.params_dtype),
+                                     requires_grad=False)
+            self.bias.output_dim, self.bias.weight_loader = 0, self.weight_loader
+        else:
+            self.register_parameter("bias", None)
+
+    def weight_loader(self, param, loaded_weight: torch.Tensor, loaded_shard_id=None) -> None:
+        output_dim = getattr(param, "output_dim", None)
+        if output_dim is None:      # replicated on every rank (g_idx of an activation-ordered GPTQ head)
+            if loaded_weight.dim() == 0:
+                loaded_weight = loaded_weight.reshape(1)
+            if param.data.shape != loaded_weight.shape:
+                raise ValueError(f"{self.prefix}: replicated tensor of shape {tuple(loaded_weight.shape)} for a "
+                                 f"parameter of shape {tuple(param.data.shape)}")
+            param.data.copy_(loaded_weight)
+            return
+        start, size, full = self.vocab_start, self.vocab_end - self.vocab_start, self.org_vocab_size
+        if getattr(param, "packed_dim", None) == output_dim:
+            f = param.packed_factor
+            start, size, full = start // f, size // f, full // f
+        if loaded_weight.shape[output_dim] != full:
+            raise ValueError(f"{self.prefix}: checkpoint tensor has {loaded_weight.shape[output_dim]} entries along the "
+                             f"vocabulary, expected {full}")
+        shard = loaded_weight.narrow(output_dim, start, size)
+        param.data.narrow(output_dim, 0, size).copy_(shard)
+        rest = param.data.shape[output_dim] - size
+        if rest:      # padding rows of the last rank
+            param.data.narrow(output_dim, size, rest).zero_()
+
+    weight_loader_v2 = weight_loader
+
+    def process_weights_after_loading(self) -> None:
+        self.quant_method.process_weights_after_loading(self)
+
+    def forward(self, input_):
+        raise RuntimeError("LMHead's weights should be used in the sampler.")

@@ -113,7 +113,9 @@ class MI355XW4A16LinearKernel(MPLinearKernel):
             return False, "Only float16/bfloat16 activations are supported"
         if c.has_g_idx and c.partition_weight_shape[0] != c.full_weight_shape[0]:
             # rows of one scale group are then spread over the ranks: the sorted order that makes
-            # groups contiguous needs the whole of K on one rank
+            # groups contiguous needs the whole of K on one rank.  The fork's own ROCm kernels refuse the
+            # same case (exllama.py:35-41; Triton and Conch refuse g_idx altogether): only its CUDA-only
+            # Marlin route serves it, through the replicated scales of auto_gptq.py:367-378.
             return False, "Activation reordering (g_idx) with the input dimension sharded is not supported"
         if c.weight_type == scalar_types.uint4 and not c.zero_points:
             return False, "uint4 weights need zero points (symmetric checkpoints use uint4b8)"
@@ -278,14 +280,16 @@ class MI355XW8A16LinearKernel(MPLinearKernel):
 
 def _act_order_perm(g_idx: torch.Tensor | None, K: int, G: int) -> torch.Tensor | None:
     """Row order that sorts a GPTQ g_idx by group (stable), or None when the rows already are in
-    group order (checkpoints written without activation reordering carry a trivial or empty g_idx)."""
+    group order (checkpoints written without activation reordering carry a trivial or empty g_idx).
+    A g_idx that was never filled in (all zeros with more than one group) is refused like any other
+    assignment that does not give every group exactly group_size rows."""
     if g_idx is None or g_idx.numel() == 0:
         return None
     if g_idx.numel() != K:
         raise ValueError(f"g_idx has {g_idx.numel()} entries for {K} input features")
     g = g_idx.to(torch.int64)
     want = torch.arange(K, device=g.device, dtype=torch.int64) // G
-    if torch.equal(g, want) or not bool(g.any()):
+    if torch.equal(g, want):
         return None
     perm = torch.argsort(g, stable=True)
     if not torch.equal(g[perm], want):

@@ -1,47 +1,139 @@
 """Registration of this package's kernels inside a running vLLM (only imported when `vllm` is
-importable).  Uses the reference's public registration points and nothing else:
+importable).  Uses the fork's public registration points and nothing else:
 
   * register_linear_kernel(cls, PlatformEnum.ROCM, "mp") appends at the lowest priority
-    (kernels/linear/__init__.py:1091-1137), so the class is moved to the front of
+    (kernels/linear/__init__.py:1091-1137), so the classes are then moved to the front of
     _POSSIBLE_KERNELS[PlatformEnum.ROCM] to win choose_mp_linear_kernel (:724-794);
   * register_backend(AttentionBackendEnum.CUSTOM, "<path>") (v1/attention/backends/registry.py
-    :242-294), selected with --attention-backend CUSTOM.
+    :242-294), selected with --attention-backend CUSTOM; MI355Q_OVERRIDE_ROCM_ATTN=1 also
+    replaces the fork's ROCM_ATTN entry, so that the platform's default choice
+    (platforms/rocm.py:470-484) lands on this backend;
+  * register_quantization_config("auto_awq" / "awq" / "awq_marlin") (quantization/__init__.py
+    :59-106): the fork's ROCm AWQ method calls ops.awq_gemm / awq_dequantize directly
+    (auto_awq.py:934-958) instead of asking for an MPLinearKernel, so the linear method is
+    replaced by a subclass that repacks once and runs the MI355X GEMM.
 
-The vLLM-side kernel class derives from vLLM's own MPLinearKernel so isinstance checks in the
-fork hold; its behaviour is the implementation in mp_kernel.MI355XW4A16LinearKernel.
+Every class handed to vLLM is a real subclass of the fork's own base class, defined here with
+explicit delegation to the implementation in this package.
 """
+import os
+
+
+def make_mp_kernel_classes():
+    """(W4A16 class, W8A16 class) deriving from the fork's MPLinearKernel."""
+    import torch
+    from vllm.model_executor.kernels.linear.mixed_precision.MPLinearKernel import MPLinearKernel as VllmMPLinearKernel
+
+    from . import mp_kernel
+
+    def _shadow(impl, c):
+        # vLLM's ScalarType objects are another class than this package's: match them by name
+        mine = {str(t): t for t in impl.SUPPORTED_QUANT_TYPES}
+        wt = mine.get(str(c.weight_type))
+        if wt is None:
+            return None, f"Quant type {c.weight_type} not supported; supported: {list(mine)}"
+        return mp_kernel.MPLinearLayerConfig(tuple(c.full_weight_shape), tuple(c.partition_weight_shape), wt,
+                                             c.act_type, c.group_size, c.zero_points, c.has_g_idx, c.out_type), None
+
+    def _derive(impl, name):
+        class Kernel(VllmMPLinearKernel):
+            __doc__ = impl.__doc__
+            SUPPORTED_QUANT_TYPES = impl.SUPPORTED_QUANT_TYPES
+
+            @classmethod
+            def get_min_capability(cls) -> int:
+                return impl.get_min_capability()
+
+            @classmethod
+            def can_implement(cls, c):
+                shadow, why = _shadow(impl, c)
+                if shadow is None:
+                    return False, why
+                return impl.can_implement(shadow)
+
+            def __init__(self, c, w_q_param_name, w_s_param_name, w_zp_param_name=None, w_gidx_param_name=None,
+                         src_layout=None, zp_mode=None):
+                ok, why = self.can_implement(c)
+                if not ok:
+                    raise ValueError(f"{name} cannot implement this layer: {why}")
+                VllmMPLinearKernel.__init__(self, c, w_q_param_name, w_s_param_name, w_zp_param_name,
+                                            w_gidx_param_name)
+                self.src_layout, self.zp_mode = src_layout, zp_mode
+
+            def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
+                impl.process_weights_after_loading(self, layer)
+
+            def apply_weights(self, layer, x, bias=None):
+                return impl.apply_weights(self, layer, x, bias)
+
+        for extra in ("apply_weights_silu_mul", "apply_weights_add_rms_norm"):
+            if hasattr(impl, extra):
+                setattr(Kernel, extra, getattr(impl, extra))
+        Kernel.__name__ = Kernel.__qualname__ = name
+        return Kernel
+
+    if not hasattr(mp_kernel.MI355XW8A16LinearKernel, "SUPPORTED_QUANT_TYPES"):
+        mp_kernel.MI355XW8A16LinearKernel.SUPPORTED_QUANT_TYPES = (mp_kernel.scalar_types.uint8b128,)
+    return (_derive(mp_kernel.MI355XW4A16LinearKernel, "MI355XW4A16LinearKernel"),
+            _derive(mp_kernel.MI355XW8A16LinearKernel, "MI355XW8A16LinearKernel"))
+
+
+def make_awq_config_class():
+    """AutoAWQConfig subclass of the fork whose plain linear method runs the MI355X kernel."""
+    import torch
+    from vllm.model_executor.layers.quantization import auto_awq as ref
+
+    from .. import _lib, ops
+
+    class AutoAWQLinearMethod(ref.AutoAWQLinearMethod):   # the name is what WEIGHT_LOADER_V2_SUPPORTED lists
+        """Checkpoint tensors are created and loaded by the fork's BaseAWQLinearMethod
+        (auto_awq.py:846-919); after loading they are repacked once into the kernel layout."""
+
+        def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
+            qc = self.quant_config
+            K = layer.qweight.shape[0]
+            G = K if qc.group_size == -1 else qc.group_size
+            w = ops.w4a16_repack(layer.qweight.data.contiguous(), layer.scales.data.contiguous(),
+                                 layer.qzeros.data.contiguous(), G, _lib.W_AWQ, _lib.ZP_AWQ)
+            for name, t in (("qweight", w.packed), ("scales", w.scales), ("qzeros", w.zc)):
+                delattr(layer, name)
+                layer.register_parameter(name, torch.nn.Parameter(t, requires_grad=False))
+            layer.mi355q_weight = ops.PackedW4(layer.qweight.data, layer.scales.data, layer.qzeros.data, w.K, w.N, G,
+                                               w.tile)
+
+        def apply(self, layer, x, bias=None):
+            return ops.w4a16_gemm(x, layer.mi355q_weight, bias=bias)
+
+    class AutoAWQConfig(ref.AutoAWQConfig):
+        def get_quant_method(self, layer, prefix):
+            m = super().get_quant_method(layer, prefix)
+            if type(m) is ref.AutoAWQLinearMethod:
+                ok = self.weight_bits == 4 and (self.group_size == -1 or self.group_size % 32 == 0)
+                return AutoAWQLinearMethod(self) if ok else m
+            return m
+
+    return AutoAWQConfig
 
 
 def hook_into_vllm() -> None:
     from vllm.model_executor.kernels.linear import _POSSIBLE_KERNELS, register_linear_kernel
-    from vllm.model_executor.kernels.linear.mixed_precision.MPLinearKernel import MPLinearKernel as VllmMPLinearKernel
+    from vllm.model_executor.layers.quantization import register_quantization_config
     from vllm.platforms.interface import PlatformEnum
+    from vllm.v1.attention.backends.registry import AttentionBackendEnum, register_backend
 
-    from . import mp_kernel
-
-    impl = mp_kernel.MI355XW4A16LinearKernel
-    body = {k: v for k, v in vars(impl).items() if not k.startswith("__") or k == "__init__"}
-    body["__doc__"] = impl.__doc__
-
-    def can_implement(cls, c):
-        # vLLM's ScalarType objects compare by value with their own kind only: go through the name
-        mine = {str(t): t for t in impl.SUPPORTED_QUANT_TYPES}
-        wt = mine.get(str(c.weight_type))
-        if wt is None:
-            return False, f"Quant type {c.weight_type} not supported; supported: {list(mine)}"
-        shadow = mp_kernel.MPLinearLayerConfig(c.full_weight_shape, c.partition_weight_shape, wt, c.act_type,
-                                               c.group_size, c.zero_points, c.has_g_idx, c.out_type)
-        return impl.can_implement.__func__(cls, shadow)
-
-    body["can_implement"] = classmethod(can_implement)
-    kernel = type("MI355XW4A16LinearKernel", (VllmMPLinearKernel,), body)
-    if not any(k.__name__ == kernel.__name__ for k in _POSSIBLE_KERNELS.get(PlatformEnum.ROCM, [])):
+    lst = _POSSIBLE_KERNELS.setdefault(PlatformEnum.ROCM, [])
+    have = {k.__name__ for k in lst}
+    for pos, kernel in enumerate(make_mp_kernel_classes()):
+        if kernel.__name__ in have:
+            continue
         register_linear_kernel(kernel, PlatformEnum.ROCM, "mp")
-        lst = _POSSIBLE_KERNELS[PlatformEnum.ROCM]
-        lst.insert(0, lst.pop(lst.index(kernel)))
+        lst.insert(pos, lst.pop(lst.index(kernel)))
 
-    try:
-        from vllm.v1.attention.backends.registry import AttentionBackendEnum, register_backend
-        register_backend(AttentionBackendEnum.CUSTOM, "mi355q.plugin.attention.Mi355AttentionBackend")
-    except Exception:  # attention registry layout differs between vLLM versions; linear kernels still work
-        pass
+    path = "mi355q.plugin.vllm_attention."
+    register_backend(AttentionBackendEnum.CUSTOM, path + "MI355XAttentionBackend")
+    if os.environ.get("MI355Q_OVERRIDE_ROCM_ATTN", "0") == "1":
+        register_backend(AttentionBackendEnum.ROCM_ATTN, path + "MI355XRocmAttnBackend")
+
+    awq = make_awq_config_class()
+    for name in ("auto_awq", "awq", "awq_marlin"):
+        register_quantization_config(name)(awq)
