@@ -6,8 +6,8 @@
  * allocator in the vLLM integration).  No entry point allocates or frees device
  * memory, synchronises the host, or touches any stream other than the one
  * passed in, so all of them can be captured into a HIP graph.  (Two kernels keep
- * arrival counters in a small static device array of the library: see
- * mi355q_paged_attention and mi355q_argmax.)
+ * arrival counters in a small static device array of the library, one bank per stream:
+ * see mi355q_paged_attention, mi355q_argmax and mi355q_reset_library_state.)
  *
  * Return value: 0 on success, a negative MI355Q_E* code otherwise;
  * mi355q_last_error() returns a thread-local message for the last failure
@@ -60,6 +60,20 @@ enum {
 
 const char* mi355q_last_error(void);
 int mi355q_version(void);
+/*
+ * The library reads its MI355Q_* environment knobs (route selection for tests and experiments,
+ * e.g. MI355Q_PA_REDUCE_KERNEL, MI355Q_ARGMAX_NARROW, MI355Q_SPLITK) once per process, at first use.
+ * This sets (value != NULL) or clears (value == NULL) one of them for the rest of the process.
+ * No reference counterpart (the reference reads vllm.envs at import).
+ */
+int mi355q_set_option(const char* name, const char* value);
+/*
+ * Zeroes the arrival counters and result slots that mi355q_paged_attention (and the two attention
+ * entry points beside it) and mi355q_argmax keep in device memory of the library.  Every call leaves
+ * them zero, so this is only needed after a launch was aborted half-way (device fault, process-level
+ * recovery).  No reference counterpart.  Launches a small kernel on `stream`.
+ */
+int mi355q_reset_library_state(mi355q_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* W4A16 dequant-GEMM                                                  */
@@ -416,11 +430,11 @@ int mi355q_convert_fp8(void* dst, const void* src, int64_t n, float scale, int d
  * argument meaning; exp_sums/max_logits [S, H, P] fp32 and tmp_out [S, H, P, D]
  * are caller-allocated scratch with P = ceil(max_seq_len / 256).
  * The partitions of a long context are merged inside the same launch by the last
- * workgroup to arrive; its arrival counters are a few KiB of device memory owned by the
- * library, zero between launches.  Attention launches that overlap on one GPU (different
- * streams) would share them: keep them on one stream, or set MI355Q_PA_REDUCE_KERNEL=1 in
- * the environment for the stateless variant with a separate merge launch.  This holds for
- * the two attention entry points below as well.
+ * workgroup to arrive; its arrival counters are device memory owned by the library, zero
+ * between launches, one bank per stream (the first four streams of a process that launch
+ * attention; later streams, grids beyond a bank of 16384 counters, or MI355Q_PA_REDUCE_KERNEL=1
+ * in the environment take the stateless variant with a separate merge launch).  This holds
+ * for the attention entry points below as well.
  */
 int mi355q_paged_attention(void* out, float* exp_sums, float* max_logits, void* tmp_out,
                            const void* query, int64_t q_stride, const void* key_cache,

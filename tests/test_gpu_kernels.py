@@ -662,13 +662,13 @@ def test_paged_attention_inline_merge_equals_merge_kernel(fp8, monkeypatch):
         qd = to_dev(q)
         outs = []
         for env in (None, "1"):
-            if env:
-                monkeypatch.setenv("MI355Q_PA_REDUCE_KERNEL", env)
-            else:
-                monkeypatch.delenv("MI355Q_PA_REDUCE_KERNEL", raising=False)
-            out = torch.full_like(qd, float("nan"))
-            ops.paged_attention_rocm(out, es, ml, tmp, qd, kcd, vcd, KVH, scale, torch.from_numpy(bt).to(DEV),
-                                     torch.from_numpy(sl).to(DEV), None, bs, max_len, None, "fp8" if fp8 else "auto", kst, vst)
+            _lib.set_option("MI355Q_PA_REDUCE_KERNEL", env)
+            try:
+                out = torch.full_like(qd, float("nan"))
+                ops.paged_attention_rocm(out, es, ml, tmp, qd, kcd, vcd, KVH, scale, torch.from_numpy(bt).to(DEV),
+                                         torch.from_numpy(sl).to(DEV), None, bs, max_len, None, "fp8" if fp8 else "auto", kst, vst)
+            finally:
+                _lib.set_option("MI355Q_PA_REDUCE_KERNEL", None)
             outs.append(out)
         # same formula in two kernels: the compiler may contract the multiply-adds differently, so a
         # handful of outputs can differ by one rounding step; anything more would be a stale read

@@ -54,9 +54,9 @@ for name, (K, N, pro) in shapes.items():
         ws = make(K, N, tile)
         for waves in (4, 8, 16):
             if tile == 64 and waves == 16: continue
-            os.environ["MI355Q_WAVES"] = str(waves)
+            _lib.set_option("MI355Q_WAVES", str(waves))
             for split in (1,):
-                os.environ["MI355Q_SPLITK"] = str(split)
+                _lib.set_option("MI355Q_SPLITK", str(split))
                 us, gbs = run(name, K, N, pro, ws)
                 print(f"{name:8s} M={M} tile={tile:2d} waves={waves:2d} split={split} : {us:7.2f} us  {gbs:7.0f} GB/s", flush=True)
         del ws

@@ -2,13 +2,13 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vllm-fork_amd"))
 import torch
-from mi355q import ops
+from mi355q import _lib, ops
 dev = "cuda:0"
 K = 4096
 for N in (28672, 28672 * 2, 28672 * 4, 28672 * 8):
     for tile, waves in ((64, 8), (64, 4), (32, 8)):
-        os.environ["MI355Q_WAVES"] = str(waves)
-        os.environ["MI355Q_SPLITK"] = "1"
+        _lib.set_option("MI355Q_WAVES", str(waves))
+        _lib.set_option("MI355Q_SPLITK", "1")
         ws = []
         for _ in range(3):
             qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=dev)

@@ -14,6 +14,7 @@
 // Softmax statistics are combined across waves through LDS; per-partition results go to
 // tmp_out / exp_sums / max_logits and a second kernel merges partitions.
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 
@@ -50,13 +51,32 @@ struct PAParams {
   unsigned long long* stamps;  // diagnostics: 10 timestamps per workgroup (8 at 100 MHz, 2 shader-clock), or null
   int k_off, v_off;
   int inline_reduce;  // 1: the workgroup that finishes a query block's last partition merges the partitions
+  int cnt_bank;       // bank of arrival counters this launch's stream owns (inline_reduce)
 };
 
 // Arrival counters of the in-kernel partition merge, one per (query block, kv head); library-owned,
-// zero between launches (the last arriver resets its counter).  Launches that overlap on one GPU
-// must not share counters: they are ordered on one stream in this library's use.
-constexpr int PA_COUNTERS = 65536;
-static __device__ int g_pa_cnt[PA_COUNTERS];
+// zero between launches (the last arriver resets its counter).  Every stream that launches attention
+// gets a bank of its own (stream_bank), so launches that overlap on different streams do not meet on a
+// counter; a process with more streams than banks, or a grid larger than a bank, takes the separate
+// merge launch instead.  mi355q_reset_library_state zeroes them after an aborted launch.
+//
+// Hand-off form (gfx950): the partial tiles and statistics are stored write-through (agent-scope
+// atomic stores = `sc1`), every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup
+// meets at a barrier, ONE lane adds to the counter with an agent-scope atomic, and the workgroup whose
+// add returned the last ticket reads every handed-off byte with agent-scope (`sc1`) loads after a
+// barrier behind that add -- stores, signal and loads all bypass the non-coherent L1 / L2 levels, so the
+// producers need no release fence; the last arriver still runs one agent-scope acquire before its loads.
+constexpr int PA_BANK = 16384;
+static __device__ int g_pa_cnt[MI355Q_STATE_BANKS * PA_BANK];
+
+__global__ void pa_reset_kernel() {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MI355Q_STATE_BANKS * PA_BANK; i += gridDim.x * blockDim.x)
+    g_pa_cnt[i] = 0;
+}
+int reset_attention_state(hipStream_t stream) {
+  hipLaunchKernelGGL(pa_reset_kernel, dim3(64), dim3(256), 0, stream);
+  return check_launch("pa_reset_kernel");
+}
 
 template <typename DT>
 __device__ inline u32x2 fp8x4_to_h16(uint32_t v) {
@@ -532,7 +552,7 @@ __global__ __launch_bounds__(256, (FUSED && !KVFP8) ? 1 : 3) void paged_attentio
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    int* cnt = g_pa_cnt + (size_t)blockIdx.x * gridDim.z + blockIdx.z;
+    int* cnt = g_pa_cnt + (size_t)p.cnt_bank * PA_BANK + (size_t)blockIdx.x * gridDim.z + blockIdx.z;
     const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == nactive - 1;
     if (last) {
@@ -622,8 +642,13 @@ template <typename DT>
 static int launch_pa(const PAParams& p_in, int head_size, int kv_fp8, int qblocks, int max_qlen,
                      hipStream_t stream, bool fused = false) {
   PAParams p = p_in;
-  // partitions are merged inside the kernel whenever the library's arrival counters cover the grid
-  p.inline_reduce = p.max_parts > 1 && (long)qblocks * p.num_kv_heads <= PA_COUNTERS && !getenv("MI355Q_PA_REDUCE_KERNEL");
+  // partitions are merged inside the kernel whenever this stream's bank of arrival counters covers the grid
+  p.cnt_bank = 0;
+  p.inline_reduce = 0;
+  if (p.max_parts > 1 && (long)qblocks * p.num_kv_heads <= PA_BANK && !env_flag("MI355Q_PA_REDUCE_KERNEL")) {
+    const int bank = stream_bank((void*)stream);
+    if (bank >= 0) { p.cnt_bank = bank; p.inline_reduce = 1; }
+  }
   dim3 grid(qblocks, p.max_parts, p.num_kv_heads), block(256);
 #define MI355Q_PA(H, F8, FU) hipLaunchKernelGGL((paged_attention_kernel<DT, H, F8, FU>), grid, block, 0, stream, p)
   if (fused) {

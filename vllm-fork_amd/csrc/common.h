@@ -6,6 +6,9 @@
 
 #include "../../include/mi355q.h"
 
+// banks of library-owned arrival counters: one per stream that uses them (stream_bank)
+#define MI355Q_STATE_BANKS 4
+
 namespace mi355q {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -19,6 +22,12 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 // error plumbing (capi.cpp)
 int set_error(int code, const char* fmt, ...);
 int check_launch(const char* what);
+// environment knobs, read once per process (capi.cpp)
+const char* env_value(const char* name);
+bool env_flag(const char* name);
+int env_int(const char* name, int dflt);
+// bank of library-owned counters for a stream, or -1 (capi.cpp)
+int stream_bank(void* stream);
 
 #define MI355Q_REQUIRE(cond, ...)                              \
   do {                                                         \

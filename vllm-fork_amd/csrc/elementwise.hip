@@ -646,17 +646,28 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const void* __restrict__ l
 // per lane; a segment's best (value, first index) becomes one 64-bit key -- order-preserving
 // image of the float in the upper half, 0x7fffffff - index in the lower -- merged with an atomic
 // max per row, and the workgroup that draws the row's last ticket decodes the key.  The per-row
-// slots live in device memory owned by the library and return to zero after every call, so calls
-// that overlap on one GPU (different streams) must not share rows below ARGMAX_ROWS; they are
-// ordered on one stream in this library's use.
+// slots live in device memory owned by the library and return to zero after every call; every stream
+// that launches the kernel gets a bank of its own (stream_bank), so calls that overlap on different
+// streams do not share slots.  mi355q_reset_library_state zeroes them after an aborted launch.
 constexpr int ARGMAX_ROWS = 1024;
 constexpr int ARGMAX_SEG_ELEMS = 8192;
-static __device__ unsigned long long g_argmax_key[ARGMAX_ROWS];
-static __device__ int g_argmax_cnt[ARGMAX_ROWS];
+static __device__ unsigned long long g_argmax_key[MI355Q_STATE_BANKS * ARGMAX_ROWS];
+static __device__ int g_argmax_cnt[MI355Q_STATE_BANKS * ARGMAX_ROWS];
+
+__global__ void argmax_reset_kernel() {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MI355Q_STATE_BANKS * ARGMAX_ROWS; i += gridDim.x * blockDim.x) {
+    g_argmax_key[i] = 0ull;
+    g_argmax_cnt[i] = 0;
+  }
+}
+int reset_argmax_state(hipStream_t stream) {
+  hipLaunchKernelGGL(argmax_reset_kernel, dim3(4), dim3(256), 0, stream);
+  return check_launch("argmax_reset_kernel");
+}
 
 template <int DTID>
 __global__ __launch_bounds__(256) void argmax_wide_kernel(const void* __restrict__ logits, int64_t row_stride,
-                                                          int64_t* __restrict__ ids, int V, int segs) {
+                                                          int64_t* __restrict__ ids, int V, int segs, int bank) {
   constexpr int ES = DTID == MI355Q_FP32 ? 4 : 2, EPV = 16 / ES;
   typedef unsigned long long u64;
   __shared__ u64 skey[4];
@@ -708,13 +719,14 @@ __global__ __launch_bounds__(256) void argmax_wide_kernel(const void* __restrict
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w2 = 1; w2 < 4; w2++) key = skey[w2] > key ? skey[w2] : key;
-    __hip_atomic_fetch_max(&g_argmax_key[rowi], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int slot = bank * ARGMAX_ROWS + rowi;
+    __hip_atomic_fetch_max(&g_argmax_key[slot], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const int ticket = __hip_atomic_fetch_add(&g_argmax_cnt[rowi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ticket = __hip_atomic_fetch_add(&g_argmax_cnt[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket == segs - 1) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      const u64 k = __hip_atomic_exchange(&g_argmax_key[rowi], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&g_argmax_cnt[rowi], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 k = __hip_atomic_exchange(&g_argmax_key[slot], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&g_argmax_cnt[slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int idx = 0x7fffffff - (int)(uint32_t)(k & 0xffffffffu);
       ids[rowi] = idx == 0x7fffffff ? 0 : idx;   // row of -inf / NaN: index 0
     }
@@ -785,7 +797,7 @@ extern "C" int mi355q_fused_add_rms_norm(void* input, int64_t input_stride, void
   MI355Q_REQUIRE(input && residual && hidden > 0 && num_tokens >= 0, "fused_add_rms_norm: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const bool aligned = hidden % 8 == 0 && input_stride % 8 == 0 && (((uintptr_t)input | (uintptr_t)residual | (uintptr_t)weight) & 15) == 0;
-  if (aligned && hidden <= 8 * 256 * 4 && !getenv("MI355Q_NORM_SCALAR")) {
+  if (aligned && hidden <= 8 * 256 * 4 && !env_flag("MI355Q_NORM_SCALAR")) {
     if (hidden <= 8 * 256 * 2) {
       DISPATCH_H16(dtype, hipLaunchKernelGGL((fused_add_rms_norm_vec_kernel<DT, 256, 2>), dim3(num_tokens), dim3(256), 0, s,
                                              (uint16_t*)input, input_stride, (uint16_t*)residual,
@@ -815,7 +827,7 @@ extern "C" int mi355q_splitk_add_rms_norm(void* out, void* residual, const float
   hipStream_t s = (hipStream_t)stream;
   const bool aligned = hidden % 4 == 0 && (((uintptr_t)out | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)bias) & 7) == 0 &&
                        ((uintptr_t)partial & 15) == 0;
-  if (aligned && hidden <= 4 * 256 * 8 && !getenv("MI355Q_NORM_SCALAR")) {
+  if (aligned && hidden <= 4 * 256 * 8 && !env_flag("MI355Q_NORM_SCALAR")) {
     const size_t sstr = (size_t)num_tokens * hidden;
     if (hidden <= 4 * 1024) {
       DISPATCH_H16(dtype, hipLaunchKernelGGL((splitk_add_rms_norm_vec_kernel<DT, 1024, 1>), dim3(num_tokens), dim3(1024), 0, s,
@@ -927,7 +939,7 @@ extern "C" int mi355q_rope_and_cache(const int64_t* positions, void* query, int6
   hipStream_t s = (hipStream_t)stream;
   const bool vec = is_neox && rot_dim == head_size && head_size % 16 == 0 && query_stride % 4 == 0 && key_stride % 4 == 0 &&
                    value_stride % 4 == 0 && (((uintptr_t)query | (uintptr_t)key | (uintptr_t)value | (uintptr_t)key_cache) & 7) == 0 &&
-                   !getenv("MI355Q_ROPE_SCALAR");
+                   !env_flag("MI355Q_ROPE_SCALAR");
   if (vec) {
     const int items = (num_heads + num_kv_heads) * head_size / 8 + num_kv_heads * head_size / 4;
     const int vthreads = items >= 1024 ? 1024 : (items + 63) / 64 * 64;
@@ -1006,15 +1018,17 @@ extern "C" int mi355q_argmax(const void* logits, int64_t row_stride, int64_t* id
   hipStream_t s = (hipStream_t)stream;
   const int es = dtype == MI355Q_FP32 ? 4 : 2;
   const int segs = std::min(vocab / ARGMAX_SEG_ELEMS, 64);
-  if (segs >= 2 && num_rows <= ARGMAX_ROWS && ((uintptr_t)logits & 15) == 0 && (row_stride * es) % 16 == 0 &&
-      !getenv("MI355Q_ARGMAX_NARROW")) {
+  const int bank = (segs >= 2 && num_rows <= ARGMAX_ROWS && ((uintptr_t)logits & 15) == 0 &&
+                    (row_stride * es) % 16 == 0 && !env_flag("MI355Q_ARGMAX_NARROW"))
+                       ? stream_bank((void*)stream) : -1;
+  if (bank >= 0) {
     const dim3 grid(num_rows, segs);
     if (dtype == MI355Q_FP32)
-      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_FP32>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs);
+      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_FP32>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs, bank);
     else if (dtype == MI355Q_BF16)
-      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_BF16>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs);
+      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_BF16>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs, bank);
     else
-      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_FP16>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs);
+      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_FP16>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs, bank);
     return check_launch("argmax_wide_kernel");
   }
   if (dtype == MI355Q_FP32)

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void linear_mfma_kernel(const uint16_t* __rest
 template <typename DT>
 static int launch_linear(const void* a, int lda, const void* w, const void* bias, void* c, int M,
                          int N, int K, hipStream_t stream) {
-  if (M >= 2 && K % 32 == 0 && !getenv("MI355Q_LINEAR_NO_MFMA")) {
+  if (M >= 2 && K % 32 == 0 && !env_flag("MI355Q_LINEAR_NO_MFMA")) {
     int rows_pp = std::min(M, 16);
     while (rows_pp > 1 && (size_t)rows_pp * (K + 8) * 2 > 128 * 1024) rows_pp--;
     const size_t lds_m = (size_t)rows_pp * (K + 8) * 2;

@@ -212,7 +212,7 @@ extern "C" size_t mi355q_w4a16_packed_bytes(int K, int N) { return (size_t)K * N
 // one workgroup, so that no cross-block split of K is needed.
 extern "C" int mi355q_w4a16_choose_tile(int K, int N, int G) {
   if (G <= 0) G = K;
-  const char* env = getenv("MI355Q_TILE");
+  const char* env = env_value("MI355Q_TILE");
   if (env && tile_ok(atoi(env), K, G)) return atoi(env);
   int sw = N >= 16384 ? 64 : (N >= 6144 ? 32 : 16);
   while (sw < 64 && !legacy_kernel_ok(sw, K, G)) sw <<= 1;   // the widths the split-K capable kernel runs
@@ -1171,7 +1171,7 @@ static Plan make_plan(int M, int N, int K, int G, int sw, bool lds_prologue, int
   const int chunks = K / (32 * CS);
   const int strips = N / sw, mts = (M + 15) / 16;
   int s = 1;
-  const char* env = getenv("MI355Q_SPLITK");
+  const char* env = env_value("MI355Q_SPLITK");
   if (split_k > 0) s = std::min(split_k, chunks);
   else if (env && atoi(env) > 0) s = std::min(atoi(env), chunks);
   else {
@@ -1183,7 +1183,7 @@ static Plan make_plan(int M, int N, int K, int G, int sw, bool lds_prologue, int
   const int per_block = (chunks + s - 1) / s;
   // 16 waves only pay off when every wave still gets several chunks of a long K
   int nw = (per_block >= 64 && sw != 64) ? 16 : 8;
-  const char* envw = getenv("MI355Q_WAVES");
+  const char* envw = env_value("MI355Q_WAVES");
   if (envw && atoi(envw) > 0) nw = std::min(sw == 64 ? 8 : 16, atoi(envw));
   while (nw > 4 && nw / 2 >= per_block) nw /= 2;
   return Plan{s, nw};
@@ -1692,7 +1692,7 @@ constexpr int MM_RT = 4;
 // 32 rows or fewer (decode batches beyond the GEMV kernels' reach): 32-row tiles, half the matrix-core
 // and accumulator work per weight chunk of the 64-row tile
 static inline int mm_rt(int M) {
-  static const int rt2_max = getenv("MI355Q_MM_RT2_MAX") ? atoi(getenv("MI355Q_MM_RT2_MAX")) : 32;
+  static const int rt2_max = env_int("MI355Q_MM_RT2_MAX", 32);
   return M <= rt2_max ? 2 : MM_RT;
 }
 
@@ -1778,7 +1778,7 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
                      ((uintptr_t)c & 7) == 0 && ((uintptr_t)zc & 15) == 0 && ((uintptr_t)bias & 7) == 0,
                  "w4a16_gemm: pointers must be 16-byte aligned");
   // several rows against the 16-channel-strip layout: strips side by side, K sliced over workgroups
-  if (!moe && pro == PRO_NONE && !epi_silu && sw == 16 && M >= ROWS_MIN_M && !getenv("MI355Q_NO_ROWS")) {
+  if (!moe && pro == PRO_NONE && !epi_silu && sw == 16 && M >= ROWS_MIN_M && !env_flag("MI355Q_NO_ROWS")) {
     RowsPlan rp = plan_rows(M, N, K, G, zc != nullptr);
     // short K: the single-strip kernel still holds every row of a pass in LDS and needs no K-slices
     const BurstPlan sb = plan_burst(M, K, G, 1, zc != nullptr);
@@ -1804,7 +1804,7 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
   {
     const int ns = sw / 16;
     BurstPlan bp = plan_burst(moe ? 1 : M, K, G, ns, zc != nullptr);
-    const char* nb = getenv("MI355Q_NO_BURST");
+    const char* nb = env_value("MI355Q_NO_BURST");
     const long blocks = moe ? (long)(N / sw) * M : (long)(N / sw) * ((M + 15) / 16);
     const bool want_split = !epi_silu && (split_k > 1 || blocks < 128);
     if (moe) {
@@ -2035,7 +2035,7 @@ extern "C" int mi355q_moe_w4a16_gemm(const void* x, int ldx, int x_row_div, cons
 extern "C" int mi355q_w4a16_choose_strip(int K, int N, int G) {
   if (G <= 0) G = K;
   const int legacy = mi355q_w4a16_choose_tile(K, N, G);
-  if (getenv("MI355Q_TILE") || (G % 128 && G != 64 && G != 32) || K % 128) return legacy;
+  if (env_flag("MI355Q_TILE") || (G % 128 && G != 64 && G != 32) || K % 128) return legacy;
   int best = 0;
   double best_cost = 1e30;
   const int cands[4] = {1, 2, 4, 7};
@@ -2121,7 +2121,7 @@ extern "C" int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const
 // 5..16 rows on 16-channel strips whose activations do not fit one workgroup's LDS: the K-sliced rows
 // kernel serves them (same choice as mi355q_w4a16_gemm makes)
 static bool rows_route(int M, int N, int K, int G, int tile, bool has_zc, RowsPlan* out) {
-  if (tile != 16 || M < ROWS_MIN_M || M >= 17 || getenv("MI355Q_NO_ROWS")) return false;
+  if (tile != 16 || M < ROWS_MIN_M || M >= 17 || env_flag("MI355Q_NO_ROWS")) return false;
   RowsPlan rp = plan_rows(M, N, K, G, has_zc);
   if (!rp.ok) return false;
   const BurstPlan sb = plan_burst(M, K, G, 1, has_zc);

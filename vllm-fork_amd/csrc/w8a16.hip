@@ -307,7 +307,7 @@ static int launch_w8a16(const void* a, int lda, const void* w, const float* scal
   const bool block_scale = block_k < K;
   const int scale_cols = block_scale ? (K + block_k - 1) / block_k : 1;
   // several rows: matrix cores (whole 64-k steps per wave; scale blocks must end on 64-k steps)
-  if (M >= 2 && K % 64 == 0 && (!block_scale || block_k % 64 == 0) && !getenv("MI355Q_W8_NO_MFMA")) {
+  if (M >= 2 && K % 64 == 0 && (!block_scale || block_k % 64 == 0) && !env_flag("MI355Q_W8_NO_MFMA")) {
     int nw = 8;
     while (nw > 1 && K % (64 * nw)) nw >>= 1;
     int rows_pp = std::min(M, 16);

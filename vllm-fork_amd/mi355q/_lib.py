@@ -27,6 +27,8 @@ c_int, c_i64, c_f32, c_sz, c_vp = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
 _SIGS = {
     "mi355q_last_error": (ctypes.c_char_p, []),
     "mi355q_version": (c_int, []),
+    "mi355q_set_option": (c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "mi355q_reset_library_state": (c_int, [c_vp]),
     "mi355q_w4a16_choose_tile": (c_int, [c_int, c_int, c_int]),
     "mi355q_w4a16_choose_strip": (c_int, [c_int, c_int, c_int]),
     "mi355q_w4a16_repack": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
@@ -119,6 +121,12 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def set_option(name: str, value: str | None) -> None:
+    """Set or clear one of the library's MI355Q_* knobs for the rest of the process (the library reads
+    the environment only once)."""
+    check(lib().mi355q_set_option(name.encode(), None if value is None else value.encode()))
 
 
 def check(status):
