@@ -431,10 +431,12 @@ int mi355q_convert_fp8(void* dst, const void* src, int64_t n, float scale, int d
  * are caller-allocated scratch with P = ceil(max_seq_len / 256).
  * The partitions of a long context are merged inside the same launch by the last
  * workgroup to arrive; its arrival counters are device memory owned by the library, zero
- * between launches, one bank per stream (the first four streams of a process that launch
+ * between launches, one bank per stream (the first 64 streams of a process that launch
  * attention; later streams, grids beyond a bank of 16384 counters, or MI355Q_PA_REDUCE_KERNEL=1
- * in the environment take the stateless variant with a separate merge launch).  This holds
- * for the attention entry points below as well.
+ * in the environment take the stateless variant with a separate merge launch).  A launch
+ * captured into a HIP graph keeps the bank of its capture stream: graphs captured on one
+ * stream must not be replayed concurrently.  This holds for the attention entry points below
+ * as well.
  */
 int mi355q_paged_attention(void* out, float* exp_sums, float* max_logits, void* tmp_out,
                            const void* query, int64_t q_stride, const void* key_cache,
@@ -446,6 +448,27 @@ int mi355q_paged_attention(void* out, float* exp_sums, float* max_logits, void* 
                            int block_size, int max_seq_len, const float* alibi_slopes,
                            int dtype, int kv_fp8, const float* k_scale, const float* v_scale,
                            mi355q_stream_t stream);
+
+/*
+ * mi355q_paged_attention for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels with exp_sums,
+ * max_logits and tmp_out taken from a device array inside the library instead of from the caller.
+ * No counterpart in the reference, whose op allocates these buffers through torch on every call
+ * (chunked_prefill_paged_decode.py:379-395).  Calls nothing that allocates or frees.
+ * Limit: num_seqs * num_heads * ceil(max_seq_len / 256) <= MI355Q_PA_NOALLOC_MAX_ITEMS
+ * (MI355Q_ENOSPACE otherwise); head_size <= 128.  The array (about 4.1 MiB) exists once per GPU the
+ * library runs on and is shared by every call on that GPU: calls that overlap on one GPU (different
+ * streams) race on it.  Nothing in it has to be zero between calls.
+ */
+#define MI355Q_PA_NOALLOC_MAX_ITEMS 16384
+int mi355q_paged_attention_noalloc(void* out, const void* query, int64_t q_stride, const void* key_cache,
+                                   const void* value_cache, int64_t kv_block_stride,
+                                   int64_t kv_head_stride, int num_seqs, int num_heads, int num_kv_heads,
+                                   int head_size, float scale, const int32_t* block_tables,
+                                   int max_blocks_per_seq, const int32_t* seq_lens,
+                                   const int32_t* query_start_loc, int block_size, int max_seq_len,
+                                   const float* alibi_slopes, int dtype, int kv_fp8, const float* k_scale,
+                                   const float* v_scale, mi355q_stream_t stream);
 
 /*
  * Attention for rows with query length >= 1 (prompt rows), reading K/V back from

@@ -74,7 +74,7 @@ __global__ void pa_reset_kernel() {
     g_pa_cnt[i] = 0;
 }
 int reset_attention_state(hipStream_t stream) {
-  hipLaunchKernelGGL(pa_reset_kernel, dim3(64), dim3(256), 0, stream);
+  hipLaunchKernelGGL(pa_reset_kernel, dim3(256), dim3(256), 0, stream);
   return check_launch("pa_reset_kernel");
 }
 
@@ -771,6 +771,66 @@ extern "C" int mi355q_decode_attention_fused(
   MI355Q_REQUIRE(((uintptr_t)cos_sin_cache & 15) == 0, "decode_attention_fused: cos_sin_cache must be 16-byte aligned");
   if (dtype == MI355Q_BF16) return launch_pa<BF16>(p, head_size, kv_fp8, num_seqs, 1, (hipStream_t)stream, true);
   return launch_pa<FP16>(p, head_size, kv_fp8, num_seqs, 1, (hipStream_t)stream, true);
+}
+
+// ---------------------------------------------------------------------------
+// Entry point that allocates nothing: the partition scratch of mi355q_paged_attention lives in a
+// device array of the library.  Each GPU holds its own copy of the array at its own address, looked
+// up once per device.
+// ---------------------------------------------------------------------------
+namespace mi355q {
+constexpr size_t NA_ITEMS = MI355Q_PA_NOALLOC_MAX_ITEMS;   // (sequence, head, partition) triples
+constexpr size_t NA_TMP_BYTES = NA_ITEMS * 128 * 2;         // tmp_out: head size <= 128, 16-bit
+constexpr size_t NA_STAT_BYTES = NA_ITEMS * 4;              // exp_sums, max_logits: fp32 each
+static __device__ __align__(256) unsigned char scratch[NA_TMP_BYTES + 2 * NA_STAT_BYTES];
+
+constexpr int NA_MAX_DEVICES = 64;
+static unsigned char* g_scratch_ptr[NA_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+// device address of this GPU's copy of `scratch` (the array's name is not an address host code may use)
+static int scratch_address(unsigned char** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NA_MAX_DEVICES)
+    return set_error(MI355Q_EHIP, "paged_attention_noalloc: cannot identify the current device");
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr)
+      return set_error(MI355Q_EHIP, "paged_attention_noalloc: hipGetSymbolAddress: %s", hipGetErrorString(e));
+    g_scratch_ptr[dev] = (unsigned char*)ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return MI355Q_OK;
+}
+}  // namespace mi355q
+
+extern "C" int mi355q_paged_attention_noalloc(
+    void* out, const void* query, int64_t q_stride, const void* key_cache, const void* value_cache,
+    int64_t kv_block_stride, int64_t kv_head_stride, int num_seqs, int num_heads, int num_kv_heads,
+    int head_size, float scale, const int32_t* block_tables, int max_blocks_per_seq,
+    const int32_t* seq_lens, const int32_t* query_start_loc, int block_size, int max_seq_len,
+    const float* alibi_slopes, int dtype, int kv_fp8, const float* k_scale, const float* v_scale,
+    mi355q_stream_t stream) {
+  if (num_seqs == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(num_seqs > 0 && num_heads > 0 && max_seq_len > 0, "paged_attention_noalloc: bad sizes");
+  const size_t parts = ((size_t)max_seq_len + MI355Q_PA_PARTITION - 1) / MI355Q_PA_PARTITION;
+  const size_t items = (size_t)num_seqs * (size_t)num_heads * parts;
+  if (items > NA_ITEMS)
+    return set_error(MI355Q_ENOSPACE,
+                     "paged_attention_noalloc: %d sequences x %d heads x %zu partitions = %zu exceeds the built-in "
+                     "scratch of %zu (use mi355q_paged_attention with caller-allocated scratch)",
+                     num_seqs, num_heads, parts, items, (size_t)NA_ITEMS);
+  unsigned char* base = nullptr;
+  if (int e = scratch_address(&base)) return e;
+  void* tmp_out = base;
+  float* exp_sums = reinterpret_cast<float*>(base + NA_TMP_BYTES);
+  float* max_logits = reinterpret_cast<float*>(base + NA_TMP_BYTES + NA_STAT_BYTES);
+  return mi355q_paged_attention(out, exp_sums, max_logits, tmp_out, query, q_stride, key_cache, value_cache,
+                                kv_block_stride, kv_head_stride, num_seqs, num_heads, num_kv_heads, head_size, scale,
+                                block_tables, max_blocks_per_seq, seq_lens, query_start_loc, block_size, max_seq_len,
+                                alibi_slopes, dtype, kv_fp8, k_scale, v_scale, stream);
 }
 
 /* Diagnostics (not part of the public ABI): per-workgroup 100 MHz timestamps of the attention kernel. */

@@ -6,8 +6,9 @@
 
 #include "../../include/mi355q.h"
 
-// banks of library-owned arrival counters: one per stream that uses them (stream_bank)
-#define MI355Q_STATE_BANKS 4
+// banks of library-owned arrival counters: one per stream that uses them (stream_bank); enough for
+// the stream pools of a torch process (32 per priority and device)
+#define MI355Q_STATE_BANKS 64
 
 namespace mi355q {
 

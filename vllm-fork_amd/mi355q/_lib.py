@@ -85,6 +85,9 @@ _SIGS = {
     "mi355q_paged_attention": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_int,
                                        c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_int,
                                        c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "mi355q_paged_attention_noalloc": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int,
+                                               c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp,
+                                               c_vp, c_vp]),
     "mi355q_paged_prefill_attention": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64,
                                                c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_vp,
                                                c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -729,6 +729,24 @@ def paged_attention_rocm(out, exp_sum, max_logits, tmp_out, query, key_cache, va
         int(_is_fp8(kv_cache_dtype)), _ptr(k_scale), _ptr(v_scale), _stream()))
 
 
+def paged_attention_noalloc(out, query, key_cache, value_cache, num_kv_heads: int, scale: float, block_tables,
+                            seq_lens, query_start_loc, block_size: int, max_seq_len: int, alibi_slopes,
+                            kv_cache_dtype: str, k_scale, v_scale) -> None:
+    """paged_attention_rocm with the partition scratch taken from a device array of the library
+    (mi355q_paged_attention_noalloc): for callers that cannot allocate.  Raises when sequences x heads x
+    partitions exceeds the built-in scratch."""
+    _need_cuda(out, query, key_cache, value_cache, block_tables, seq_lens)
+    if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise RuntimeError("paged_attention_noalloc: block_tables and seq_lens must be int32")
+    S = block_tables.shape[0]
+    H, D = query.shape[1], query.shape[2]
+    check(_lib.lib().mi355q_paged_attention_noalloc(
+        out.data_ptr(), query.data_ptr(), query.stride(0), key_cache.data_ptr(), value_cache.data_ptr(),
+        key_cache.stride(0), key_cache.stride(1), S, H, num_kv_heads, D, scale, block_tables.data_ptr(),
+        block_tables.shape[1], seq_lens.data_ptr(), _ptr(query_start_loc), block_size, max_seq_len,
+        _ptr(alibi_slopes), _dt(query), int(_is_fp8(kv_cache_dtype)), _ptr(k_scale), _ptr(v_scale), _stream()))
+
+
 def paged_prefill_attention(out, exp_sum, max_logits, tmp_out, query, key_cache, value_cache, num_kv_heads: int,
                             scale: float, block_tables, seq_lens, query_start_loc, max_query_len: int,
                             block_size: int, max_seq_len: int, alibi_slopes, kv_cache_dtype: str, k_scale,
