@@ -624,7 +624,8 @@ def test_paged_attention_vs_oracle(H, KVH, D, bs, fp8):
     vst = torch.tensor(vs, dtype=torch.float32, device=DEV)
     ops.paged_attention_rocm(out, es, ml, tmp, qd, kcd, vcd, KVH, scale, torch.from_numpy(bt).to(DEV),
                              torch.from_numpy(sl).to(DEV), None, bs, max(lens), None, "fp8" if fp8 else "auto", kst, vst)
-    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-5, atol=2e-3 if not fp8 else 1e-2)
+    # tolerance of the reference's test of its kernel (tests/kernels/attention/test_attention.py:288-291)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-5, atol=1e-3 if not fp8 else 1e-2)
 
 
 @pytest.mark.parametrize("fp8", [False, True])
