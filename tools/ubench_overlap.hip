@@ -1,0 +1,163 @@
+// Microbenchmark: can dependent weight-streaming kernels overlap their launch boundary on gfx950?
+// A decode layer is a chain of kernels, each of which streams its own weights once and needs the small
+// output vector of its predecessor.  Stream order makes kernel i+1 wait for the END of kernel i before it
+// even starts, so the memory system idles for the boundary, the prologue and the first round trip of
+// every launch.  Here consecutive kernels go to two alternating streams (two parallel chains in one
+// graph) and the data dependency is carried by a counter in memory instead: kernel i+1 starts while
+// kernel i is still running, requests its first ring of weights, and only then waits for the counter.
+//   build: hipcc -O3 --offload-arch=gfx950 tools/ubench_overlap.hip -o tools/ubench_overlap
+// Every spin loop gives up after a bounded time and records an error, so a runtime that serialises the
+// two chains in the wrong order ends with a wrong result instead of a hang.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <unistd.h>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+struct Link {
+  const unsigned* flag_in;  // counter the predecessor's workgroups bump when their output is visible (null: none)
+  unsigned need_in;         // its value once every one of them has
+  unsigned* flag_out;       // this kernel's own counter (null: none)
+  unsigned* err;            // set to 1 by a workgroup whose wait ran out
+};
+
+template <int DEPTH>
+__global__ __launch_bounds__(512, 2) void ovl_k(const u32x4* __restrict__ w, long vecs_per_wg, const unsigned* x_in, int xwords,
+                                                unsigned* x_out, Link lk, unsigned long long spin_limit) {
+  __shared__ unsigned red[16];
+  __shared__ unsigned s_x[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const long per_wave = vecs_per_wg / nw;
+  const u32x4* p = w + (long)blockIdx.x * vecs_per_wg + (long)wave * per_wave + lane;
+  const long steps = per_wave / 64;
+  u32x4 buf[DEPTH];
+#pragma unroll
+  for (int i = 0; i < DEPTH; i++) buf[i] = __builtin_nontemporal_load(p + (long)(i < steps ? i : 0) * 64);
+  // wait for the predecessor, then read its output past this CU's L1 and this XCD's stale L2 lines
+  if (lk.flag_in) {
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(lk.flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lk.need_in) {
+        __builtin_amdgcn_s_sleep(4);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > spin_limit) { *lk.err = 1; break; }
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 256) s_x[threadIdx.x] = __hip_atomic_load(x_in + (threadIdx.x % xwords), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  unsigned acc = s_x[lane] ^ s_x[lane + 64] ^ s_x[lane + 128] ^ s_x[lane + 192];
+  for (long s = 0; s < steps; s += DEPTH) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; i++) {
+      u32x4 v = buf[i];
+      if (s + i < steps) acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+      if (s + DEPTH + i < steps) buf[i] = __builtin_nontemporal_load(p + (s + DEPTH + i) * 64);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc ^= __shfl_xor(acc, o, 64);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int i = 0; i < nw; i++) t ^= red[i];
+    __hip_atomic_store(x_out + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+    if (lk.flag_out) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(lk.flag_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+struct Stage { double mb; int wgs; };
+
+// mode 0: one stream, no counters (stream order carries the dependency)
+// mode 1: one stream, counters (what the protocol itself costs when nothing overlaps)
+// mode 2: two alternating streams, counters
+template <int DEPTH>
+static float run(hipStream_t sa, hipStream_t sb, const u32x4* weights, size_t total_vecs, unsigned* xbuf, unsigned* flags, unsigned* err,
+                 const std::vector<Stage>& stages, int layers, int mode, double* checksum) {
+  hipGraph_t g; hipGraphExec_t ge;
+  hipEvent_t fork, join; hipEventCreateWithFlags(&fork, hipEventDisableTiming); hipEventCreateWithFlags(&join, hipEventDisableTiming);
+  const int nk = layers * (int)stages.size();
+  hipStreamBeginCapture(sa, hipStreamCaptureModeGlobal);
+  hipMemsetAsync(flags, 0, sizeof(unsigned) * (nk + 1), sa);
+  if (mode == 2) { hipEventRecord(fork, sa); hipStreamWaitEvent(sb, fork, 0); }
+  size_t off = 0;
+  int k = 0, prev_wgs = 0;
+  for (int l = 0; l < layers; l++)
+    for (const Stage& s : stages) {
+      long vpw = (long)(s.mb * 1e6 / 16 / s.wgs) / (8 * 64) * (8 * 64);
+      if (vpw == 0) vpw = 8 * 64;
+      if (off + (size_t)vpw * s.wgs > total_vecs) off = 0;
+      hipStream_t st = (mode == 2 && (k & 1)) ? sb : sa;
+      Link lk = {nullptr, 0, nullptr, err};
+      if (mode >= 1) {
+        lk.flag_in = k ? flags + k - 1 : nullptr;
+        lk.need_in = prev_wgs;
+        lk.flag_out = flags + k;
+      }
+      // x ping-pongs over three buffers: a kernel two places down the chain may start while the reader of
+      // the buffer it writes is still running only if they share a stream, which two buffers would allow
+      unsigned* xin = xbuf + 256 * (k % 3);
+      unsigned* xout = xbuf + 256 * ((k + 1) % 3);
+      hipLaunchKernelGGL((ovl_k<DEPTH>), dim3(s.wgs), dim3(512), 0, st, weights + off, vpw, xin, 256, xout, lk, 100ull * 100000ull /* 100 ms */);
+      off += (size_t)vpw * s.wgs;
+      prev_wgs = s.wgs;
+      k++;
+    }
+  if (mode == 2) { hipEventRecord(join, sb); hipStreamWaitEvent(sa, join, 0); }
+  hipStreamEndCapture(sa, &g);
+  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { printf("instantiate failed\n"); return -1.f; }
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 2; i++) hipGraphLaunch(ge, sa);
+  hipStreamSynchronize(sa);
+  hipEventRecord(a, sa);
+  const int reps = 5;
+  for (int i = 0; i < reps; i++) hipGraphLaunch(ge, sa);
+  hipEventRecord(b, sa);
+  hipStreamSynchronize(sa);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  unsigned h[768]; hipMemcpy(h, xbuf, sizeof(h), hipMemcpyDeviceToHost);
+  double cs = 0; for (int i = 0; i < 768; i++) cs += h[i] * (i + 1.0);
+  *checksum = cs;
+  hipGraphExecDestroy(ge); hipGraphDestroy(g);
+  return ms * 1000.f / (reps * layers);
+}
+
+int main() {
+  hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+  const size_t bytes = (size_t)3600 << 20;
+  u32x4* w; CK(hipMalloc(&w, bytes));
+  // distinct words, so that a kernel that ran on a stale input vector changes the checksum
+  {
+    std::vector<unsigned> h(bytes / 4 / 64);
+    for (size_t i = 0; i < h.size(); i++) h[i] = (unsigned)(i * 2654435761u) ^ 0x5bd1e995u;
+    for (int r = 0; r < 64; r++) CK(hipMemcpy((char*)w + (size_t)r * h.size() * 4, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  }
+  unsigned *xbuf, *flags, *err;
+  CK(hipMalloc(&xbuf, 4096)); CK(hipMemset(xbuf, 0, 4096));
+  CK(hipMalloc(&flags, 8192)); CK(hipMemset(flags, 0, 8192)); err = flags + 1500;
+  CK(hipDeviceSynchronize());
+  const size_t total_vecs = bytes / 16;
+  const int layers = 32;
+  std::vector<Stage> layer = {{13.0, 192}, {0.9, 8}, {8.65, 256}, {60.6, 256}, {30.3, 256}};
+  const char* names[3] = {"one stream, stream order", "one stream, counters", "two streams, counters"};
+#define RUN(D)                                                                                                           \
+  for (int mode = 0; mode < 3; mode++) {                                                                                 \
+    double cs;                                                                                                           \
+    float t = run<D>(sa, sb, w, total_vecs, xbuf, flags, err, layer, layers, mode, &cs);                                 \
+    unsigned ran_out = 0; CK(hipMemcpy(&ran_out, err, 4, hipMemcpyDeviceToHost));                                                        \
+    printf("depth %2d  %-26s layer %6.2f us  checksum %.0f  wait-ran-out %u\n", D, names[mode], t, cs, ran_out);               \
+    fflush(stdout);                                                                                                      \
+    if (ran_out) { fflush(stdout); _exit(2); }                                                                                                   \
+  }
+  RUN(4);
+  RUN(8);
+  RUN(14);
+  return 0;
+}

@@ -138,7 +138,12 @@ __global__ __launch_bounds__(256, (FUSED && !KVFP8) ? 1 : 3) void paged_attentio
   PA_STAMP(8);
 
   int seq, q0, qlen, qstart;
-  if (p.varlen) {
+  if constexpr (FUSED) {   // the fused decode step only exists for one new token per sequence
+    seq = blockIdx.x;
+    q0 = 0;
+    qlen = 1;
+    qstart = seq;
+  } else if (p.varlen) {
     seq = blockIdx.x / p.qblocks_per_seq;
     q0 = (blockIdx.x % p.qblocks_per_seq) * QB;
     qstart = p.qsl[seq];
@@ -154,10 +159,15 @@ __global__ __launch_bounds__(256, (FUSED && !KVFP8) ? 1 : 3) void paged_attentio
       if (p.qsl[seq + 1] - qstart != 1) return;  // prompt rows are not handled here
     }
   }
-  // Plain decode rows: the block-table entries and the query fragments depend on the block index
-  // only, so they are requested before the sequence length is known (one round trip saved).
+  // The kernel is latency-bound at decode sizes, so its memory requests are arranged in two dependent
+  // groups and nothing else: (1) everything addressed by the block index alone -- sequence length,
+  // position, this wave's block-table entries, the query fragments, the new token's key and value --
+  // and (2) everything addressed by what group 1 returned -- cos/sin of the position, the K and V
+  // tiles.  Every request is unconditional (addresses are clamped into valid memory and the results
+  // masked afterwards): a load under a lane-dependent branch makes the compiler drain the whole
+  // vector-memory queue at the join, which turns each such branch into one more round trip.
   constexpr int DS = HEAD / 32;
-  const bool plain = !p.varlen && !p.qsl;
+  const bool plain = FUSED || (!p.varlen && !p.qsl);
   int phys_pre[4] = {0, 0, 0, 0};
   u32x4 qf[DS];
   if (plain) {
@@ -175,9 +185,32 @@ __global__ __launch_bounds__(256, (FUSED && !KVFP8) ? 1 : 3) void paged_attentio
       qf[ds] = *reinterpret_cast<const u32x4*>(qp0 + d0);
     }
   }
-  const int64_t pos = FUSED ? p.positions[seq] : 0;
+  // new token: thread t < HEAD/2 rotates key pair (t, t + HEAD/2), thread 128 + d carries value d; the
+  // other threads read the same few lines again and ignore them
+  uint16_t nk_x = 0, nk_y = 0, nk_c = 0, nk_s = 0, nv = 0;
+  if constexpr (FUSED) {
+    const uint16_t* rowp = p.q + (size_t)seq * p.q_stride;
+    const uint16_t* kp = rowp + p.k_off + blockIdx.z * HEAD;
+    const int tk = threadIdx.x & (HEAD / 2 - 1);
+    nk_x = kp[tk];
+    nk_y = kp[tk + HEAD / 2];
+    nv = rowp[p.v_off + blockIdx.z * HEAD + (threadIdx.x & (HEAD - 1))];
+  }
+  int64_t pos = FUSED ? p.positions[seq] : 0;
   const float kscale = KVFP8 ? *p.k_scale : 1.0f, vscale = KVFP8 ? *p.v_scale : 1.0f;  // requested with the rest
-  const int seq_len = p.seq_lens[seq];
+  int seq_len = p.seq_lens[seq];
+  // Pin the first group in front of the early exit below.  Left alone, the compiler sinks every load
+  // whose result the exit path does not need behind that branch, i.e. behind the round trip of the
+  // sequence length.  Touching one register of each load here costs nothing: they were requested
+  // together and return together.
+  if (plain) {
+    uint32_t t0 = nk_x, t1 = nk_y, t2 = nv;
+    int64_t ps = pos;
+    asm volatile("" : "+v"(seq_len), "+v"(ps), "+v"(phys_pre[0]), "+v"(phys_pre[1]), "+v"(phys_pre[2]), "+v"(phys_pre[3]),
+                      "+v"(qf[0][0]), "+v"(qf[DS / 2][0]), "+v"(qf[DS - 1][0]), "+v"(t0), "+v"(t1), "+v"(t2));
+    nk_x = (uint16_t)t0; nk_y = (uint16_t)t1; nv = (uint16_t)t2;
+    pos = ps;
+  }
   const int q_in_blk = min(QB, qlen - q0);
   const int blk_ctx = seq_len - qlen + q0 + q_in_blk;  // tokens visible to the last column
   const int part = blockIdx.y;
@@ -210,13 +243,11 @@ __global__ __launch_bounds__(256, (FUSED && !KVFP8) ? 1 : 3) void paged_attentio
     }
   }
 
-  // Fused decode step: everything the new token needs is requested here, together with the
-  // cache reads below, so that one memory round trip serves the whole kernel; its arithmetic
-  // (RoPE, cache write, patching the new token into the K/V fragments) follows the requests.
+  // ---- second group: cos/sin of the position, the cache block of the new token, K and V tiles ------
   u32x4 cfrag[FUSED ? DS / 2 : 1], sfrag[FUSED ? DS / 2 : 1];
   const int tnew = seq_len - 1;
   const bool owns_new = FUSED && part == tnew / MI355Q_PA_PARTITION;
-  uint16_t nk_x = 0, nk_y = 0, nk_c = 0, nk_s = 0, nv = 0;
+  int blk_new = 0;
   if constexpr (FUSED) {
     const uint16_t* cs = p.cos_sin + (size_t)pos * HEAD;
 #pragma unroll
@@ -225,22 +256,16 @@ __global__ __launch_bounds__(256, (FUSED && !KVFP8) ? 1 : 3) void paged_attentio
       cfrag[ds] = *reinterpret_cast<const u32x4*>(cs + d0);
       sfrag[ds] = *reinterpret_cast<const u32x4*>(cs + HEAD / 2 + d0);
     }
-    if (owns_new) {
-      const uint16_t* rowp = p.q + (size_t)qstart * p.q_stride;
-      const int t = threadIdx.x;
-      if (t < HEAD / 2) {
-        const uint16_t* kp = rowp + p.k_off + kvh * HEAD;
-        nk_x = kp[t]; nk_y = kp[t + HEAD / 2];
-        nk_c = cs[t]; nk_s = cs[HEAD / 2 + t];
-      } else if (t >= 128 && t < 128 + HEAD) {
-        nv = rowp[p.v_off + kvh * HEAD + (t - 128)];
-      }
-    }
+    const int tk = threadIdx.x & (HEAD / 2 - 1);
+    nk_c = cs[tk];
+    nk_s = cs[HEAD / 2 + tk];
+    blk_new = table[min(tnew / p.bs, p.max_blocks - 1)];
   }
 
-  // ---- request K and V of the wave's four 16-token tiles -----------------------------------
   // K: A operand rows = tokens; V^T: rows = head dims, k = tokens in the permuted order of the
-  // P fragment (element j <-> token 4 kq + j of the even tile, j >= 4: of the odd tile)
+  // P fragment (element j <-> token 4 kq + j of the even tile, j >= 4: of the odd tile).
+  // A tile past the visible context reads cache block 0 (always mapped) and is masked out below:
+  // block-table entries out there are not the caller's to keep valid.
   constexpr int DTILES = HEAD / 16;
   constexpr int KR = KVFP8 ? DS / 2 : DS;
   int phys[4];
@@ -249,59 +274,58 @@ __global__ __launch_bounds__(256, (FUSED && !KVFP8) ? 1 : 3) void paged_attentio
 #pragma unroll
   for (int T = 0; T < 4; T++) {
     const int t0 = wave_t0 + T * 16;
-    phys[T] = t0 < blk_ctx ? (plain ? phys_pre[T] : table[t0 / p.bs]) : -1;
+    const int entry = plain ? phys_pre[T] : table[min(t0 / p.bs, p.max_blocks - 1)];
+    phys[T] = t0 < blk_ctx ? entry : -1;
   }
 #pragma unroll
   for (int T = 0; T < 4; T++) {
-    if (phys[T] >= 0) {
-      const int t0 = wave_t0 + T * 16;
-      const int off = t0 % p.bs + col;  // this lane's token row of the tile
-      if constexpr (!KVFP8) {
-        const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.kc) +
-                             (size_t)phys[T] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+    const int blk = max(phys[T], 0);
+    const int t0 = wave_t0 + T * 16;
+    const int off = t0 % p.bs + col;  // this lane's token row of the tile
+    if constexpr (!KVFP8) {
+      const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.kc) +
+                           (size_t)blk * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
 #pragma unroll
-        for (int ds = 0; ds < DS; ds++)
-          kreg[T][ds] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(ds * 4 + kq) * p.bs + off) * 8);
-      } else {
-        const uint8_t* kb = reinterpret_cast<const uint8_t*>(p.kc) +
-                            (size_t)phys[T] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+      for (int ds = 0; ds < DS; ds++)
+        kreg[T][ds] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(ds * 4 + kq) * p.bs + off) * 8);
+    } else {
+      const uint8_t* kb = reinterpret_cast<const uint8_t*>(p.kc) +
+                          (size_t)blk * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
 #pragma unroll
-        for (int sp = 0; sp < DS / 2; sp++)
-          kreg[T][sp] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(sp * 4 + kq) * p.bs + off) * 16);
-      }
+      for (int sp = 0; sp < DS / 2; sp++)
+        kreg[T][sp] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(sp * 4 + kq) * p.bs + off) * 16);
     }
   }
 #pragma unroll
   for (int T = 0; T < 4; T++) {
-    if (phys[T] >= 0) {
-      const int offv = (wave_t0 + T * 16) % p.bs + 4 * kq;
-      if constexpr (!KVFP8) {
-        const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.vc) +
-                             (size_t)phys[T] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+    const int blk = max(phys[T], 0);
+    const int offv = (wave_t0 + T * 16) % p.bs + 4 * kq;
+    if constexpr (!KVFP8) {
+      const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.vc) +
+                           (size_t)blk * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
 #pragma unroll
-        for (int dt = 0; dt < DTILES; dt++)
-          vreg[T][dt] = *reinterpret_cast<const u32x2*>(vb + (size_t)(dt * 16 + col) * p.bs + offv);
-      } else {
-        const uint8_t* vb = reinterpret_cast<const uint8_t*>(p.vc) +
-                            (size_t)phys[T] * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+      for (int dt = 0; dt < DTILES; dt++)
+        vreg[T][dt] = *reinterpret_cast<const u32x2*>(vb + (size_t)(dt * 16 + col) * p.bs + offv);
+    } else {
+      const uint8_t* vb = reinterpret_cast<const uint8_t*>(p.vc) +
+                          (size_t)blk * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
 #pragma unroll
-        for (int dt = 0; dt < DTILES; dt++) {
-          vreg[T][dt][0] = *reinterpret_cast<const uint32_t*>(vb + (size_t)(dt * 16 + col) * p.bs + offv);
-          vreg[T][dt][1] = 0u;
-        }
+      for (int dt = 0; dt < DTILES; dt++) {
+        vreg[T][dt][0] = *reinterpret_cast<const uint32_t*>(vb + (size_t)(dt * 16 + col) * p.bs + offv);
+        vreg[T][dt][1] = 0u;
       }
     }
   }
 
   if constexpr (FUSED) {
-    // The new token's raw values are first touched HERE, after every cache read has been requested:
+    // cos/sin of the new key are first touched HERE, after every cache read has been requested:
     // otherwise the compiler converts them right behind their loads and the wait for that round
     // trip lands in front of the K/V requests (loads return in order, so waiting for these older
     // ones here leaves the K/V reads in flight).
     {
-      uint32_t t0 = nk_x, t1 = nk_y, t2 = nk_c, t3 = nk_s, t4 = nv;
-      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4));
-      nk_x = (uint16_t)t0; nk_y = (uint16_t)t1; nk_c = (uint16_t)t2; nk_s = (uint16_t)t3; nv = (uint16_t)t4;
+      uint32_t t2 = nk_c, t3 = nk_s;
+      asm volatile("" : "+v"(t2), "+v"(t3));
+      nk_c = (uint16_t)t2; nk_s = (uint16_t)t3;
     }
     // RoPE on the query fragments: the partner d + HEAD/2 of every element sits in fragment
     // ds + DS/2 of the same lane
@@ -312,7 +336,7 @@ __global__ __launch_bounds__(256, (FUSED && !KVFP8) ? 1 : 3) void paged_attentio
     // value to the cache (nobody waits for those stores: this step's reads of that slot are
     // replaced below) and shares them through LDS in the form the cache holds them.
     if (owns_new) {
-      const int blk = table[tnew / p.bs], off = tnew % p.bs;
+      const int blk = blk_new, off = tnew % p.bs;
       constexpr int X = KVFP8 ? 16 : 8;
       const size_t base = (size_t)blk * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
       const int t = threadIdx.x;

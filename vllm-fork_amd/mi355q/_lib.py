@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmi355q.so")
+LIB_PATH = os.environ.get("MI355Q_LIB_PATH") or os.path.join(_HERE, "lib", "libmi355q.so")   # override: kernel experiments
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "mi355q.h"))
 
 OK, EINVAL, ENOSPACE, EHIP = 0, -1, -2, -3
