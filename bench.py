@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec)
+STREAM_PEAK_GBS = 6290.0  # best sustained read rate of a pure streaming kernel measured on this chip
 
 
 def parse():
@@ -104,32 +105,51 @@ def time_dominant_kernel(runner, batch, reps=10):
         nbytes += 3 * batch * K * 2 + K * 2
     if runner.quant != "none" and layers[0]["gate_up"].w.pair_halves:   # the SiLU epilogue writes N/2 per row
         nbytes -= batch * (N // 2) * 2
+    traffic, traffic_source = pmc_traffic(runner, batch, fused)
     return {"bound": "hbm", "achieved": nbytes / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": nbytes / avg / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(runner, batch, fused),
+            "frac": nbytes / avg / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "frac_of_measured_stream_peak": nbytes / avg / 1e9 / STREAM_PEAK_GBS,
             "kernel": "w4a16_burst_kernel (gate_up_proj %dx%d%s + SiLU epilogue, M=%d)"
                       % (K, N, " + add/RMSNorm prologue" if fused else "", batch),
             "bytes_per_launch": nbytes, "avg_launch_us": avg * 1e6, "min_launch_us": min(times) * 1e6,  # best replay, per launch
-           
             "launches": len(times) * passes * len(layers)}
 
 
+PMC_FILE = os.path.join(ROOT, "profiles", "r2", "decode_8b_gptq_pmc_fetch_write.json")
+KERNEL_SOURCES = ("vllm-fork_amd/csrc/w4a16.hip", "vllm-fork_amd/csrc/common.h")
+
+
+def kernel_source_digest():
+    """sha256 over the sources the dominant kernel is built from (what the counter passes are tied to)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(runner, batch, fused):
-    """HBM bytes per launch of the dominant kernel from the committed counter passes (rocprofv3
-    cannot run inside this process): 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of
-    16-byte-per-lane streaming reads at 64 bytes) + WRITE_SIZE, both KiB per dispatch.  Only
-    valid for the workload the passes were taken on (Llama-3-8B GPTQ, TP=1, batch 1); None
-    otherwise."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1",
-                        "decode_8b_gptq_pmc_fetch_write.json")
-    if not (fused and batch == 1 and runner.tp_size == 1 and runner.cfg.name == "llama3-8b"
-            and runner.quant == "gptq" and os.path.exists(path)):
-        return None
-    with open(path) as fh:
-        rows = json.load(fh)
-    for name, row in rows.items():
-        if "w4a16_burst_kernel<mi355q::BF16, 7, 2, false, 2>" in name:
-            return (2.0 * row["fetch_size_kb_avg"] + row["write_size_kb_avg"]) * 1024.0
-    return None
+    """HBM bytes per launch of the dominant kernel from counter passes taken OUTSIDE this run (rocprofv3
+    cannot attach to its own process): 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of
+    16-byte-per-lane streaming reads at 64 bytes) + WRITE_SIZE, both KiB per dispatch.  The file records
+    the digest of the kernel sources and the kernel's template name at the time of the passes; if either
+    differs from this tree, or the workload is not the one the passes ran (Llama-3-8B GPTQ, TP=1,
+    batch 1), there is no measured traffic for this run and the result is (None, reason)."""
+    if not (fused and batch == 1 and runner.tp_size == 1 and runner.cfg.name == "llama3-8b" and runner.quant == "gptq"):
+        return None, "no counter passes for this workload"
+    if not os.path.exists(PMC_FILE):
+        return None, "no counter passes committed"
+    with open(PMC_FILE) as fh:
+        rec = json.load(fh)
+    if rec.get("kernel_source_sha256") != kernel_source_digest():
+        return None, "kernel sources changed since the counter passes (%s)" % os.path.relpath(PMC_FILE, ROOT)
+    row = rec["kernels"].get(rec["dominant_kernel"])
+    if row is None:
+        return None, "dominant kernel missing from the counter passes"
+    return (2.0 * row["fetch_size_kb_avg"] + row["write_size_kb_avg"]) * 1024.0, \
+        "%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel build (%s), %d dispatches" % (
+            os.path.relpath(PMC_FILE, ROOT), rec["dominant_kernel"], row["dispatches"])
 
 
 def cpu_baseline(cfg, G, batch, budget_s=15.0):
@@ -173,6 +193,29 @@ def cpu_baseline(cfg, G, batch, budget_s=15.0):
                       "restatement, 16-channel block layout) for the 4 projections of all %d layers + the bf16 "
                       "lm_head, batch %d; attention/norms excluded" % (steps, cfg.layers, batch),
             "sample_seconds": el}
+
+
+def cpu_baseline_opt125m(budget_s=6.0):
+    """OPT-125m-shaped bf16 greedy decode (the reference's CPU-backend plumbing case: LayerNorm, learned
+    positions, ReLU MLP, tied lm_head) in the oracle, random-init weights, one sequence, prompt of 32
+    tokens; decode steps are timed until about `budget_s` seconds have been spent."""
+    import numpy as np
+    from oracle import opt125m
+    cores = len(os.sched_getaffinity(0))
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    w = opt125m.make_weights(0)
+    d = opt125m.OptDecoder(w, max_len=2048)
+    tok = d.forward(np.arange(5, 37, dtype=np.int64))
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        tok = d.forward(np.asarray([tok], dtype=np.int64))
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 1900:
+            break
+    return {"value": steps / el, "unit": "tok/s", "cores": cores, "kind": "port",
+            "sample": "%d greedy decode steps of an OPT-125m-shaped bf16 model (12 layers, hidden 768, vocab 50272) in "
+                      "oracle/opt125m.py, batch 1, prompt 32" % steps, "sample_seconds": el}
 
 
 def main():
@@ -285,12 +328,14 @@ def main():
         "step_bytes_per_gpu": step_bytes,
         "step_hbm_gbs_per_gpu": step_bytes / step_s / 1e9,
         "step_hbm_frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+        "step_hbm_frac_of_measured_stream_peak": step_bytes / step_s / 1e9 / STREAM_PEAK_GBS,
         "last_token_ids": last_ids[:4],
     }
     if rank == 0:
         out["roofline"] = time_dominant_kernel(runner, B)
     if rank == 0 and n_gpus == 1 and not args.skip_cpu:
         out["cpu_baseline"] = cpu_baseline(cfg, G, B)
+        out["cpu_baseline_opt125m"] = cpu_baseline_opt125m()
     if rank == 0 and n_gpus == 1 and args.quant != "none" and not args.skip_bf16:
         # the same harness on the unquantized model: the "x its own bf16 decode" comparator
         runner = None

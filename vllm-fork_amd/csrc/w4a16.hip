@@ -830,7 +830,11 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
 #endif
   constexpr int RING = CPW * NS;                                         // planes per wave
   constexpr int FPW = NS * CPW >= 7 ? 4 : 2;                             // 8 x 4 or 16 x 2 KiB per CU
-  constexpr int FPQ = MI355Q_BURST_FP == 0 ? RING : (MI355Q_BURST_FP == 1 ? FPW : (MI355Q_BURST_FP < 0 ? NS : MI355Q_BURST_FP));
+#ifndef MI355Q_BURST_FP_SMALL
+#define MI355Q_BURST_FP_SMALL -1
+#endif
+  constexpr int FPB = MI355Q_BURST_FP == 0 ? RING : (MI355Q_BURST_FP == 1 ? FPW : (MI355Q_BURST_FP < 0 ? NS : MI355Q_BURST_FP));
+  constexpr int FPQ = (NS * CPW < 7 && MI355Q_BURST_FP_SMALL >= 0) ? (MI355Q_BURST_FP_SMALL == 0 ? RING : MI355Q_BURST_FP_SMALL) : FPB;
   constexpr int FP = FPQ < RING ? FPQ : RING;
   auto issue_plane = [&](int f) {   // plane f of the first ring fill
     const int i = f / NS, pl = f % NS;
