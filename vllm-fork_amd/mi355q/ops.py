@@ -154,7 +154,7 @@ def w4a16_gemm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, s
             act = torch.empty((M, w.K), dtype=x.dtype, device=x.device)
             silu_and_mul(act, x2.contiguous())
             x2 = act
-        res = torch.matmul(x2, w4a16_dequantize(w), out=out)
+        res = torch.matmul(x2, w4a16_dequantize(w, out=_dequant_stage(w)), out=out)
         if bias is not None:
             res.add_(bias)
         return res.reshape(x.shape[:-1] + (w.N,))
@@ -319,10 +319,30 @@ def unpair_halves(y: torch.Tensor) -> torch.Tensor:
     return torch.cat((y[..., 0::2], y[..., 1::2]), dim=-1)
 
 
-def w4a16_dequantize(w: PackedW4) -> torch.Tensor:
+_DQ_STAGE: dict = {}
+
+
+def _dequant_stage(w: PackedW4) -> torch.Tensor:
+    """Per-device staging buffer for the expanded weights of ONE layer call on the many-token route
+    (sized for the largest layer seen, reused by every later call: the route allocates nothing in steady
+    state).  Calls on one device share it, so they must be stream-ordered -- they are: the buffer is
+    written and consumed inside one w4a16_gemm call."""
+    key = (w.packed.device, w.scales.dtype)
+    need = w.K * w.N
+    buf = _DQ_STAGE.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=w.scales.dtype, device=w.packed.device)
+        _DQ_STAGE[key] = buf
+    return buf[:need].view(w.K, w.N)
+
+
+def w4a16_dequantize(w: PackedW4, out: torch.Tensor | None = None) -> torch.Tensor:
     """[K, N] dequantised weight.  Stands in for ops.awq_dequantize (vllm/_custom_ops.py:491-505)."""
     _need_cuda(w.packed)
-    out = torch.empty((w.K, w.N), dtype=w.scales.dtype, device=w.packed.device)
+    if out is None:
+        out = torch.empty((w.K, w.N), dtype=w.scales.dtype, device=w.packed.device)
+    elif out.shape != (w.K, w.N) or out.dtype != w.scales.dtype or not out.is_contiguous():
+        raise RuntimeError(f"out must be a contiguous [{w.K}, {w.N}] tensor of the scales' dtype")
     check(_lib.lib().mi355q_w4a16_dequantize(w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc),
                                              out.data_ptr(), w.K, w.N, w.G, w.tile, _dt(w.scales), _stream()))
     return out
