@@ -81,19 +81,21 @@ def test_fused_layers_need_consistent_configs():
 
 
 def test_validation_of_the_global_values():
-    with pytest.raises(ValueError, match="Unsupported weight_bits"):
+    with pytest.raises(ValueError, match="weight_bits=5 is not one of"):
         make_config(weight_bits=5)
-    with pytest.raises(ValueError, match="Unsupported data_type"):
+    with pytest.raises(ValueError, match="data_type='nf4' is not one of"):
         make_config(data_type="nf4")
-    with pytest.raises(ValueError, match="Unsupported packing_format"):
+    with pytest.raises(ValueError, match="packing_format='gguf' is not one of"):
         make_config(packing_format="gguf")
-    with pytest.raises(ValueError, match="Unsupported backend"):
+    with pytest.raises(ValueError, match="backend='exllama' is not one of"):
         make_config(backend="exllama")
-    with pytest.raises(ValueError, match="requires an 'mx_fp' data_type"):
+    with pytest.raises(ValueError, match="only goes with a microscaling"):
         make_config(packing_format="auto_round:llm_compressor")
     c = make_config(weight_bits=8, group_size=32, packing_format="auto_round:llm_compressor", data_type="mx_fp")
     assert c.is_mxfp8 and c.weight_bits == 8
-    with pytest.raises(AssertionError, match="act_dynamic=True"):
+    with pytest.raises(AssertionError, match="needs group_size=32"):
+        make_config(weight_bits=8, group_size=128, packing_format="auto_round:llm_compressor", data_type="mx_fp")
+    with pytest.raises(AssertionError, match="needs act_dynamic=True"):
         INCConfig.from_config({"bits": 8, "group_size": 32, "sym": True, "packing_format": "auto_round:llm_compressor",
                                "data_type": "mx_fp", "act_bits": 8, "act_data_type": "mx_fp", "act_group_size": 32,
                                "act_sym": True, "act_dynamic": False})

@@ -301,43 +301,74 @@ def resolve_scheme(layer_config: INCLayerConfig) -> INCScheme:
     raise NotImplementedError(f"No INC scheme found for layer config: {layer_config}")
 
 
+# What a checkpoint-level AutoRound config may say.  The accepted values are the reference's
+# (inc/inc.py:35-52); the checks below are driven from these tables.
+_CHOICES: dict[str, tuple] = {
+    "weight_bits": (2, 3, 4, 8),
+    "packing_format": ("auto_round:auto_gptq", "auto_round:auto_awq", "auto_round:llm_compressor"),
+    "backend": ("auto", "gptq", "gptq:marlin", "awq", "awq:marlin", "marlin"),
+}
+_PLAIN_DATA_TYPES = ("int", "mx_fp")      # any other name containing "mx_fp" is a microscaling variant and passes
+_MX_PACKING = "auto_round:llm_compressor"
+# 8-bit microscaling pins these: weight side from the constructor arguments, activation side from
+# the raw checkpoint dict (a key that is absent counts as the pinned value)
+_MX8_WEIGHT_SIDE = {"group_size": 32, "sym": True, "packing_format": _MX_PACKING, "backend": "auto"}
+_MX8_ACT_SIDE = {"act_bits": 8, "act_data_type": "mx_fp", "act_group_size": 32, "act_sym": True,
+                 "act_dynamic": True, "enable_quanted_input": False}
+# checkpoint key(s) -> constructor argument, default when absent (no default: the key is required)
+_FROM_CHECKPOINT: tuple = (
+    (("bits",), "weight_bits"),
+    (("group_size",), "group_size"),
+    (("sym",), "sym"),
+    (("packing_format",), "packing_format", "auto_round:auto_gptq"),
+    (("block_name_to_quantize", "to_quant_block_names"), "block_name_to_quantize", None),
+    (("extra_config",), "extra_config", None),
+    (("data_type",), "data_type", "int"),
+    (("backend", "vllm_backend"), "backend", "auto"),
+)
+
+
+def _require_choice(what: str, value, allowed) -> None:
+    if value not in allowed:
+        raise ValueError(f"auto-round config: {what}={value!r} is not one of {list(allowed)}")
+
+
+def _require_pinned(what: str, got: dict, pinned: dict) -> None:
+    for key, want in pinned.items():
+        if got[key] != want:
+            raise AssertionError(f"auto-round config: {what} needs {key}={want!r}, the checkpoint has {key}={got[key]!r}")
+
+
 @register_quantization_config("inc")
 class INCConfig(QuantizationConfig):
-    """inc.py:32-261."""
-
-    SUPPORTED_BITS = {2, 3, 4, 8}
-    SUPPORTED_DTYPES = {"int", "mx_fp"}
-    SUPPORTED_FORMATS = {"auto_round:auto_gptq", "auto_round:auto_awq", "auto_round:llm_compressor"}
-    SUPPORTED_BACKENDS = {"auto", "gptq", "gptq:marlin", "awq", "awq:marlin", "marlin"}
-    MXFP8_BITS = 8
-    MXFP8_GROUP_SIZE = 32
-    MXFP8_DATA_TYPE = "mx_fp"
-    MXFP8_PACKING_FORMAT = "auto_round:llm_compressor"
+    """Checkpoint-level AutoRound settings; same constructor arguments, attributes, accepted values and
+    exception types as the reference's INCConfig (inc/inc.py:32-261)."""
 
     def __init__(self, weight_bits: int, group_size: int, sym: bool = True,
                  packing_format: str = "auto_round:auto_gptq",
                  block_name_to_quantize: str | list[str] | None = None,
                  extra_config: dict[str, Any] | None = None, data_type: str = "int", backend: str = "auto") -> None:
         super().__init__()
-        if weight_bits not in self.SUPPORTED_BITS:
-            raise ValueError(f"Unsupported weight_bits: {weight_bits}, currently only support {self.SUPPORTED_BITS}.")
-        is_mxfp = "mx_fp" in data_type
-        if data_type not in self.SUPPORTED_DTYPES and not is_mxfp:
-            raise ValueError(f"Unsupported data_type: {data_type}, currently only support {self.SUPPORTED_DTYPES}.")
-        if packing_format not in self.SUPPORTED_FORMATS:
-            raise ValueError(f"Unsupported packing_format: {packing_format}, "
-                             f"currently only support {self.SUPPORTED_FORMATS}.")
-        if backend not in self.SUPPORTED_BACKENDS:
-            raise ValueError(f"Unsupported backend: {backend}, currently only support {self.SUPPORTED_BACKENDS}.")
+        given = {"weight_bits": weight_bits, "packing_format": packing_format, "backend": backend}
+        # reported in the reference's order: bits, data type, packing format, backend
+        _require_choice("weight_bits", weight_bits, _CHOICES["weight_bits"])
+        if "mx_fp" not in data_type:
+            _require_choice("data_type", data_type, _PLAIN_DATA_TYPES)
+        for name in ("packing_format", "backend"):
+            _require_choice(name, given[name], _CHOICES[name])
+        if isinstance(block_name_to_quantize, str):
+            block_name_to_quantize = block_name_to_quantize.split(",")
         self.weight_bits, self.group_size, self.sym = weight_bits, group_size, sym
-        self.packing_format = packing_format
-        self.block_name_to_quantize = (block_name_to_quantize.split(",") if isinstance(block_name_to_quantize, str)
-                                       else block_name_to_quantize)
+        self.packing_format, self.backend, self.data_type = packing_format, backend, data_type
+        self.block_name_to_quantize = block_name_to_quantize
         self.extra_config = extra_config
-        self.data_type, self.backend = data_type, backend
         self.pack_factor = Fraction(32, weight_bits)
         self.config_parser = INCConfigParser(self)
-        self._validate_supported_quantization()
+        if self.is_mxfp8:
+            _require_pinned("8-bit microscaling", vars(self), _MX8_WEIGHT_SIDE)
+        elif packing_format == _MX_PACKING and not self.is_mxfp:
+            raise ValueError(f"auto-round config: packing_format={_MX_PACKING!r} only goes with a microscaling "
+                             f"('mx_fp') data_type, not {data_type!r}")
 
     def __repr__(self) -> str:
         return f"INCConfig(weight_bits={self.weight_bits}, group_size={self.group_size}, sym={self.sym})"
@@ -348,30 +379,7 @@ class INCConfig(QuantizationConfig):
 
     @property
     def is_mxfp8(self) -> bool:
-        return self.is_mxfp and self.weight_bits == self.MXFP8_BITS
-
-    def _validate_supported_quantization(self) -> None:
-        if self.is_mxfp8:
-            assert self.group_size == self.MXFP8_GROUP_SIZE, \
-                f"INC MXFP8 only supports group_size=32, but found group_size={self.group_size}."
-            assert self.sym, "INC MXFP8 only supports symmetric weights."
-            assert self.packing_format == self.MXFP8_PACKING_FORMAT, \
-                (f"INC MXFP8 only supports packing_format={self.MXFP8_PACKING_FORMAT!r}, "
-                 f"but found {self.packing_format!r}.")
-            assert self.backend == "auto", f"INC MXFP8 only supports backend='auto', but found backend={self.backend!r}."
-        elif self.packing_format == self.MXFP8_PACKING_FORMAT and not self.is_mxfp:
-            raise ValueError(f"packing_format={self.MXFP8_PACKING_FORMAT!r} requires "
-                             f"an {self.MXFP8_DATA_TYPE!r} data_type.")
-
-    def _validate_raw_config(self, config: dict[str, Any]) -> None:
-        if not self.is_mxfp8:
-            return
-        expected = {"act_bits": self.MXFP8_BITS, "act_data_type": self.MXFP8_DATA_TYPE,
-                    "act_group_size": self.MXFP8_GROUP_SIZE, "act_sym": True, "act_dynamic": True,
-                    "enable_quanted_input": False}
-        for name, want in expected.items():
-            got = self.get_from_keys_or(config, [name], want)
-            assert got == want, f"INC MXFP8 only supports {name}={want!r}, but found {name}={got!r}."
+        return self.is_mxfp and self.weight_bits == 8
 
     @classmethod
     def get_name(cls) -> str:
@@ -391,16 +399,13 @@ class INCConfig(QuantizationConfig):
 
     @classmethod
     def from_config(cls, config: dict[str, Any]) -> "INCConfig":
-        qc = cls(weight_bits=cls.get_from_keys(config, ["bits"]),
-                 group_size=cls.get_from_keys(config, ["group_size"]),
-                 sym=cls.get_from_keys(config, ["sym"]),
-                 packing_format=cls.get_from_keys_or(config, ["packing_format"], "auto_round:auto_gptq"),
-                 block_name_to_quantize=cls.get_from_keys_or(
-                     config, ["block_name_to_quantize", "to_quant_block_names"], None),
-                 extra_config=cls.get_from_keys_or(config, ["extra_config"], None),
-                 data_type=cls.get_from_keys_or(config, ["data_type"], "int"),
-                 backend=cls.get_from_keys_or(config, ["backend", "vllm_backend"], "auto"))
-        qc._validate_raw_config(config)
+        kwargs = {}
+        for keys, arg, *default in _FROM_CHECKPOINT:
+            kwargs[arg] = cls.get_from_keys_or(config, list(keys), default[0]) if default else cls.get_from_keys(config, list(keys))
+        qc = cls(**kwargs)
+        if qc.is_mxfp8:
+            seen = {key: cls.get_from_keys_or(config, [key], want) for key, want in _MX8_ACT_SIDE.items()}
+            _require_pinned("8-bit microscaling", seen, _MX8_ACT_SIDE)
         return qc
 
     def get_layer_config(self, layer, layer_name: str):
