@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--skip-bf16", action="store_true")
     ap.add_argument("--skip-ttft", action="store_true")
     ap.add_argument("--skip-shapes", action="store_true", help="skip the other (batch, input_len) shapes")
+    ap.add_argument("--tokens-out", default=None, help="rank 0 writes every decoded token id here (JSON), for TP comparisons")
     return ap.parse_args()
 
 
@@ -276,14 +277,22 @@ def main():
 
     # ---- decode ------------------------------------------------------------------------------
     graph = not args.no_graph and not (world > 1 and torch.distributed.get_backend() == "gloo")
+    graph_error = None
     if graph:
         try:
             runner.capture()
         except Exception as e:  # noqa: BLE001
+            graph_error = f"{type(e).__name__}: {e}"[:300]
             if rank == 0:
-                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                print(f"[bench] graph capture failed ({graph_error}); running eagerly", file=sys.stderr)
             graph = False
             runner.graph = None
+        if world > 1:   # every rank must take the same path: one eager rank would deadlock the others' replays
+            flag = torch.tensor([1 if graph else 0], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if int(flag.item()) == 0 and graph:
+                graph, graph_error = False, "another rank failed to capture"
+                runner.graph = None
     for _ in range(args.warmup):
         runner.decode_step()
 
@@ -291,14 +300,20 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    trace = []
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.decode_step()
+        if args.tokens_out:     # untimed use only: the copy synchronises every step
+            trace.append(runner.tokens.cpu().tolist())
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.tokens_out and rank == 0:
+        with open(args.tokens_out, "w") as fh:
+            json.dump(trace, fh)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -325,6 +340,8 @@ def main():
             model, args.quant, world, B, in_len, "fp8-e4m3" if args.kv_dtype == "fp8" else "bf16",
             "hipGraph" if graph else "eager"), "parallelism": "tp%d" % world, "batch": B, "input_len": in_len},
         "ttft_ms_p50": ttft,
+        "graph": bool(graph),          # false: capture (of the RCCL all-reduce at N > 1) failed or was disabled; eager steps timed
+        "graph_error": graph_error,
         "step_bytes_per_gpu": step_bytes,
         "step_hbm_gbs_per_gpu": step_bytes / step_s / 1e9,
         "step_hbm_frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,

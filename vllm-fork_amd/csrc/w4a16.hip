@@ -1855,7 +1855,8 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
     BurstPlan bp = plan_burst(moe ? 1 : M, K, G, ns, zc != nullptr);
     const char* nb = env_value("MI355Q_NO_BURST");
     const long blocks = moe ? (long)(N / sw) * M : (long)(N / sw) * ((M + 15) / 16);
-    const bool want_split = !epi_silu && (split_k > 1 || blocks < 128);
+    static const int split_below = env_int("MI355Q_SPLIT_BELOW", 64);   // fewer strips than this: K-sliced kernel (80 strips of 8192 k: 5.9 us here, 7.6 K-sliced)
+    const bool want_split = !epi_silu && (split_k > 1 || blocks < split_below);
     if (moe) {
       bp.ok = bp.ok && pro != PRO_ADDNORM && bias == nullptr && moe->expert_ids && moe->x_row_div >= 1;
       bp.rows_pp = 1;

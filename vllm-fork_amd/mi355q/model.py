@@ -72,19 +72,72 @@ def decode_bytes_per_step(cfg: LlamaConfig, batch: int, ctx: int, G: int, zeros:
     return total
 
 
+def _shard(kind: str, full: torch.Tensor, rows_dim: int, cols_dim: int, packed_dim, pack: int, tp_rank: int, tp_size: int,
+           parts, kv_replicas: int = 1) -> torch.Tensor:
+    """This rank's shard of one FULL checkpoint tensor, cut by the parameter loaders the linear layers use
+    (plugin/parameter.py, the reference's parameter.py:148-230): `row` narrows the input dimension,
+    `column` the output dimension, `merged` / `qkv` the output dimension per logical sub-matrix.
+    `parts`: [(shard_id, full_width)] of the logical sub-matrices along the output dimension."""
+    from .plugin import parallel
+    from .plugin.parameter import PackedvLLMParameter
+    saved = dict(parallel._STATE)
+    parallel._STATE.update(rank=tp_rank, size=tp_size)
+    try:
+        shape = list(full.shape)
+        if kind == "row":
+            shape[rows_dim] //= tp_size
+        else:
+            shape[cols_dim] = sum((w // (tp_size // kv_replicas if sid in ("k", "v") and kv_replicas > 1 else tp_size))
+                                  for sid, w in parts) // (pack if packed_dim == cols_dim else 1)
+        prm = PackedvLLMParameter(torch.empty(shape, dtype=full.dtype, device=full.device), input_dim=rows_dim,
+                                  output_dim=cols_dim, packed_dim=packed_dim if packed_dim is not None else cols_dim,
+                                  packed_factor=pack if packed_dim is not None else 1)
+        if kind == "row":
+            prm.load_row_parallel_weight(full)
+        elif kind == "column":
+            prm.load_column_parallel_weight(full)
+        else:
+            src_off = dst_off = 0
+            for sid, width in parts:
+                fw = width // (pack if packed_dim == cols_dim else 1)
+                piece = full.narrow(cols_dim, src_off, fw)
+                local = width // (tp_size // kv_replicas if sid in ("k", "v") and kv_replicas > 1 else tp_size)
+                if kind == "qkv":
+                    prm.load_qkv_weight(piece, shard_offset=dst_off, shard_size=local, shard_id=sid, num_heads=kv_replicas)
+                else:
+                    prm.load_merged_column_weight(piece, shard_offset=dst_off, shard_size=local)
+                src_off += fw
+                dst_off += local
+        return prm.data
+    finally:
+        parallel._STATE.update(saved)
+
+
 class Linear4:
-    """One quantized projection: checkpoint-layout tensors -> kernel layout -> apply."""
+    """One quantized projection: synthetic FULL checkpoint tensors (the same on every rank) -> this rank's
+    shard -> kernel layout -> apply."""
 
     def __init__(self, K, N, G, dtype, device, gen, asym: bool, gain: float = 1.0, keep_checkpoint: bool = False,
-                 pair_halves: bool = False):
+                 pair_halves: bool = False, shard=("replicated", None), tp_rank: int = 0, tp_size: int = 1,
+                 kv_replicas: int = 1):
+        """K, N: the FULL layer; shard = (kind, parts) as `_shard` takes them."""
         self.checkpoint = None
+        kind, parts = shard
         qweight = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=device, generator=gen)
         # (q - 8) has variance 21.25: keep the projection roughly norm-preserving
         s = gain / (21.25 * K) ** 0.5
         scales = (s * (0.5 + torch.rand((K // G, N), device=device, generator=gen))).to(dtype)
+        qzeros = None
         if asym:  # AWQ checkpoint tensors: N-packed AWQ order + packed zero points
             qweight = qweight.view(-1)[: K * N // 8].view(K, N // 8)
             qzeros = torch.randint(-2**31, 2**31 - 1, (K // G, N // 8), dtype=torch.int32, device=device, generator=gen)
+        if tp_size > 1 and kind != "replicated":
+            cut = lambda t, packed_dim, pack: _shard(kind, t, 0, 1, packed_dim, pack, tp_rank, tp_size, parts, kv_replicas)
+            if asym:    # [K, N/8], [K/G, N], [K/G, N/8]: packed along the output dimension
+                qweight, scales, qzeros = cut(qweight, 1, 8), cut(scales, None, 1), cut(qzeros, 1, 8)
+            else:       # [K/8, N] packed along the input dimension, [K/G, N]
+                qweight, scales = cut(qweight, 0, 8), cut(scales, None, 1)
+        if asym:
             self.w = ops.w4a16_repack(qweight, scales, qzeros, G, _lib.W_AWQ, _lib.ZP_AWQ, pair_halves=pair_halves)
             if keep_checkpoint:
                 self.checkpoint = ("awq", qweight.cpu(), scales.cpu(), qzeros.cpu(), G)
@@ -99,10 +152,16 @@ class Linear4:
 
 
 class Linear16:
-    """Unquantized projection (the bf16 comparator model)."""
+    """Unquantized projection (the bf16 comparator model); weight [N, K] cut like the quantized ones."""
 
-    def __init__(self, K, N, dtype, device, gen, gain: float = 1.0):
-        self.weight = (torch.randn((N, K), device=device, generator=gen) * (gain / K ** 0.5)).to(dtype)
+    def __init__(self, K, N, dtype, device, gen, gain: float = 1.0, shard=("replicated", None), tp_rank: int = 0,
+                 tp_size: int = 1, kv_replicas: int = 1):
+        w = (torch.randn((N, K), device=device, generator=gen) * (gain / K ** 0.5)).to(dtype)
+        kind, parts = shard
+        if tp_size > 1 and kind != "replicated":
+            # the loaders see [K, N] orientation: input dimension 0, output dimension 1
+            w = _shard(kind, w.t().contiguous(), 0, 1, None, 1, tp_rank, tp_size, parts, kv_replicas).t().contiguous()
+        self.weight = w
 
     def __call__(self, x, fuse_silu_mul=False):
         if fuse_silu_mul:
@@ -128,17 +187,30 @@ class LlamaRunner:
         self.fp8 = kv_cache_dtype.startswith("fp8")
         self.block_size, self.max_batch = block_size, max_batch
         self.max_seq_len = max_seq_len
+        # ONE synthetic checkpoint: every rank draws the same full-size tensors (same seed, same order) and
+        # keeps its own shard, so the TP = N model is the TP = 1 model
         gen = torch.Generator(device=self.device)
-        gen.manual_seed(seed + 1000 * tp_rank)
-        shapes = linear_shapes(cfg, tp_size)
+        gen.manual_seed(seed)
+        shapes = linear_shapes(cfg, tp_size)       # per rank: what the kernels see
+        full = linear_shapes(cfg, 1)               # the checkpoint's
+        assert cfg.heads % tp_size == 0 and (cfg.kv_heads % tp_size == 0 or tp_size % cfg.kv_heads == 0)
         self.heads = cfg.heads // tp_size
         self.kv_heads = max(cfg.kv_heads // tp_size, 1)
+        kv_replicas = max(tp_size // cfg.kv_heads, 1)   # ranks that share one KV head (linear.py QKVParallelLinear)
         D = cfg.head_dim
+        cuts = {
+            "qkv": ("qkv", [("q", cfg.heads * D), ("k", cfg.kv_heads * D), ("v", cfg.kv_heads * D)]),
+            "o": ("row", None),
+            "gate_up": ("merged", [("gate", cfg.inter), ("up", cfg.inter)]),
+            "down": ("row", None),
+        }
 
-        def make(K, N, gain=1.0, pair_halves=False):
+        def make(name, gain=1.0, pair_halves=False):
+            K, N = full[name]
+            kw = dict(shard=cuts[name], tp_rank=tp_rank, tp_size=tp_size, kv_replicas=kv_replicas)
             if quant == "none":
-                return Linear16(K, N, dtype, self.device, gen, gain)
-            return Linear4(K, N, self.G, dtype, self.device, gen, quant == "awq", gain, keep_checkpoint, pair_halves)
+                return Linear16(K, N, dtype, self.device, gen, gain, **kw)
+            return Linear4(K, N, self.G, dtype, self.device, gen, quant == "awq", gain, keep_checkpoint, pair_halves, **kw)
 
         # gate_i next to up_i lets the gate_up kernel finish SiluAndMul itself (decode path)
         pair = quant != "none" and ops.w4a16_gate_up_silu_supported(*shapes["gate_up"], self.G)
@@ -148,18 +220,20 @@ class LlamaRunner:
             self.layers.append({
                 "ln1": torch.ones(cfg.hidden, dtype=dtype, device=self.device),
                 "ln2": torch.ones(cfg.hidden, dtype=dtype, device=self.device),
-                "qkv": make(*shapes["qkv"]),
-                "o": make(*shapes["o"], gain=0.5),
-                "gate_up": make(*shapes["gate_up"], pair_halves=pair),
-                "down": make(*shapes["down"], gain=0.5),
+                "qkv": make("qkv"),
+                "o": make("o", gain=0.5),
+                "gate_up": make("gate_up", pair_halves=pair),
+                "down": make("down", gain=0.5),
             })
         self.norm = torch.ones(cfg.hidden, dtype=dtype, device=self.device)
         vshard = cfg.vocab // tp_size
-        # embedding replicated, lm_head vocab-parallel
+        # embedding replicated, lm_head vocab-parallel (rows of one full matrix)
         g2 = torch.Generator(device=self.device)
         g2.manual_seed(seed + 7)
         self.embed = (torch.randn((cfg.vocab, cfg.hidden), device=self.device, generator=g2) * 0.02).to(dtype)
-        self.lm_head = (torch.randn((vshard, cfg.hidden), device=self.device, generator=gen) * 0.02).to(dtype)
+        lm_full = (torch.randn((cfg.vocab, cfg.hidden), device=self.device, generator=gen) * 0.02).to(dtype)
+        self.lm_head = lm_full[tp_rank * vshard:(tp_rank + 1) * vshard].clone() if tp_size > 1 else lm_full
+        del lm_full
 
         # RoPE cache (rotary_embedding/base.py:80-103), cast to the activation dtype (:105-131)
         inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float) / D))
