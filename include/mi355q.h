@@ -519,6 +519,19 @@ int mi355q_decode_attention_fused(
  * launches that overlap on one GPU would share the slots: keep them on one stream. */
 int mi355q_argmax(const void* logits, int64_t row_stride, int64_t* ids, int num_rows, int vocab,
                   int dtype, mi355q_stream_t stream);
+
+/* Random sampling with top-k / top-p: ids[b] = argmax_i softmax(mask(logits[b] / temperature[b]))[i] / noise[b, i],
+ * first index on ties.  mask keeps the top_k[b] largest logits (ties with the k-th kept; top_k NULL,
+ * <= 0 or >= vocab: no top-k), then drops the longest ascending prefix whose cumulative probability
+ * stays <= 1 - top_p[b] and never the largest token (top_p NULL or >= 1: no top-p).  noise holds the
+ * caller's Exp(1) draws (torch's exponential_ under the request generators), so the random stream stays
+ * the caller's.  fp32 logits, one workgroup per row, thresholds by radix selection (no sort).
+ * Replaces apply_top_k_top_p_pytorch + random_sample (vllm/v1/sample/ops/topk_topp_sampler.py:367-407,
+ * 441-466) behind Sampler.sample (vllm/v1/sample/sampler.py:228-302).  Tokens with equal logits at a
+ * threshold are kept or dropped together (the reference orders them by an unspecified sort). */
+int mi355q_sample_topk_topp(const float* logits, int64_t row_stride, const float* temperature,
+                            const int32_t* top_k, const float* top_p, const float* noise, int64_t* ids,
+                            int num_rows, int vocab, mi355q_stream_t stream);
 /* In place; masks are bool (1 byte) [B, V]; penalties [B] in logits dtype.
  * Replaces ops.apply_repetition_penalties_ (vllm/_custom_ops.py:325-333;
  * sampler.cu:13-49,618-659). */

@@ -289,6 +289,40 @@ def argmax_f32(logits):
     return ids
 
 
+def top_k_top_p_mask(logits, top_k=None, top_p=None):
+    """apply_top_k_top_p_pytorch (vllm/v1/sample/ops/topk_topp_sampler.py:367-407) on fp32 [B, V]: sort
+    ascending, mask everything below the k-th largest, softmax + cumulative sum of the sorted row, mask
+    where the sum is <= 1 - p (never the last), scatter back.  Returns the masked copy."""
+    x = np.array(logits, dtype=np.float32, copy=True)
+    B, V = x.shape
+    for b in range(B):
+        idx = np.argsort(x[b], kind="stable")
+        srt = x[b][idx]
+        if top_k is not None:
+            kth = srt[V - int(top_k[b])]
+            srt[srt < kth] = -np.inf
+        if top_p is not None:
+            e = np.exp(srt - srt[-1], dtype=np.float32)
+            probs = e / e.sum(dtype=np.float32)
+            drop = np.cumsum(probs, dtype=np.float32) <= np.float32(1.0) - np.float32(top_p[b])
+            drop[-1] = False
+            srt[drop] = -np.inf
+        x[b][idx] = srt
+    return x
+
+
+def sample_topk_topp(logits, temperature, top_k, top_p, noise):
+    """Sampler.sample for random rows (vllm/v1/sample/sampler.py:263-302): logits / temperature, the masks
+    above, softmax in fp32, argmax(probs / noise) with noise ~ Exp(1) (topk_topp_sampler.py:427-438)."""
+    x = np.asarray(logits, dtype=np.float32)
+    if temperature is not None:
+        x = x / np.asarray(temperature, dtype=np.float32)[:, None]
+    m = top_k_top_p_mask(x, top_k, top_p)
+    e = np.exp(m - m.max(axis=1, keepdims=True), dtype=np.float32)
+    probs = e / e.sum(axis=1, keepdims=True, dtype=np.float32)
+    return np.argmax(probs / np.asarray(noise, dtype=np.float32), axis=1).astype(np.int64)
+
+
 def apply_repetition_penalties(logits, prompt_mask, output_mask, penalties):
     lg = np.array(logits, dtype=np.float32, copy=True, order="C")
     B, V = lg.shape

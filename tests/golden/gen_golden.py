@@ -424,6 +424,37 @@ def gen_paged_attn():
 
 
 # --------------------------------------------------------------------------
+# G9b: random sampling with top-k / top-p -- the reference's own functions
+# (vllm/v1/sample/ops/topk_topp_sampler.py: apply_top_k_top_p_pytorch :367-407,
+# random_sample :441-466), imported and run on CPU with seeded per-request generators.
+# --------------------------------------------------------------------------
+def gen_sampler_topk_topp():
+    tk = imp("vllm.v1.sample.ops.topk_topp_sampler")
+    torch.manual_seed(1)
+    B, V = 8, 8192
+    logits = (torch.randn(B, V) * 2.5).float()
+    logits[3, 100:140] = -float("inf")            # masked vocabulary entries
+    temperature = torch.tensor([1.0, 0.7, 1.3, 1.0, 0.5, 2.0, 1.0, 0.9])
+    k = torch.tensor([V, 50, 1, 40, V, 1000, 5, 300], dtype=torch.int32)
+    p = torch.tensor([1.0, 1.0, 0.9, 0.95, 0.8, 0.5, 0.3, 0.99])
+    scaled = logits / temperature.unsqueeze(1)
+    masked = tk.apply_top_k_top_p_pytorch(scaled.clone(), k, p)
+    generators = {i: torch.Generator().manual_seed(100 + i) for i in range(B)}
+    # the noise the reference draws (same generators, same call order as random_sample)
+    noise = torch.empty(B, V)
+    for i in range(B):
+        noise[i].exponential_(generator=torch.Generator().manual_seed(100 + i))
+    probs = masked.softmax(dim=-1, dtype=torch.float32)
+    ids = tk.random_sample(probs.clone(), generators)
+    assert torch.equal(ids, (probs / noise).argmax(dim=-1)), "noise replay differs from random_sample"
+    # how decisive every draw is: ratio of the second-best score to the best
+    sc = probs / noise
+    top2 = sc.topk(2, dim=-1).values
+    save("sampler_topk_topp", logits=logits.numpy(), temperature=temperature.numpy(), top_k=k.numpy(), top_p=p.numpy(),
+         noise=noise.numpy(), masked=masked.numpy(), ids=ids.numpy(), runner_up_ratio=(top2[:, 1] / top2[:, 0]).numpy())
+
+
+# --------------------------------------------------------------------------
 # G9: sampler inner loop.  Greedy = logits.float().argmax(-1)
 # (vllm/v1/sample/sampler.py:96,240-241; restated: the module derives from
 # msgspec.Struct and cannot be imported with a stub) and repetition penalties
@@ -575,7 +606,7 @@ def gen_moe():
 
 
 GENERATORS = {"pack": gen_pack, "quantize": gen_quantize, "w4a16": gen_w4a16, "awq": gen_awq, "rmsnorm": gen_rmsnorm,
-              "rope": gen_rope, "paged_attn": gen_paged_attn, "sampler": gen_sampler, "w8a16": gen_w8a16, "moe": gen_moe}
+              "rope": gen_rope, "paged_attn": gen_paged_attn, "sampler": gen_sampler, "sampler_topk_topp": gen_sampler_topk_topp, "w8a16": gen_w8a16, "moe": gen_moe}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or GENERATORS):

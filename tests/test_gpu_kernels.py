@@ -1173,3 +1173,71 @@ def test_w4a16_gate_up_silu(M, K, I, awq, norm):
     assert (to_bits(plain) == y).mean() > 0.98
     deq = ops.unpair_halves(ops.w4a16_dequantize(w))
     assert np.array_equal(to_bits(deq), orc.f32_to_h16(orc.w4a16_dequant(qw, s, qz, G=G, **kw)))
+
+
+# ---- random sampling with top-k / top-p ---------------------------------------------------------
+def _kept(masked_row):
+    return ~np.isneginf(masked_row)
+
+
+@pytest.mark.gpu
+def test_sample_topk_topp_vs_reference_golden(golden):
+    """The HIP sampler against the outputs of the reference's apply_top_k_top_p_pytorch + random_sample
+    (tests/golden/sampler_topk_topp.npz, topk_topp_sampler.py:367-407, 441-466): same token for every
+    row (the golden records how decisive each draw was: runner-up / best score, all far from 1)."""
+    d = golden("sampler_topk_topp")
+    assert d["runner_up_ratio"].max() < 0.999
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ids = ops.sample_topk_topp(t(d["logits"]), t(d["temperature"]), t(d["top_k"]), t(d["top_p"]), t(d["noise"]))
+    assert np.array_equal(ids.cpu().numpy(), d["ids"])
+    # and through the Sampler module (temperature, masks and draw in one call)
+    from mi355q.plugin.sampler import Sampler, SamplingMetadata
+    B = d["logits"].shape[0]
+    md = SamplingMetadata(temperature=t(d["temperature"]), all_greedy=False, all_random=True, top_p=t(d["top_p"]),
+                          top_k=t(d["top_k"]), generators={i: torch.Generator(device=dev).manual_seed(5 + i) for i in range(B)})
+    out = Sampler()(t(d["logits"]), md).sampled_token_ids.view(-1).cpu().numpy()
+    scaled = d["logits"] / d["temperature"][:, None]
+    masked = orc.top_k_top_p_mask(scaled, d["top_k"], d["top_p"])
+    assert all(_kept(masked[b])[out[b]] for b in range(B))   # whatever the GPU generators drew, the token survives both masks
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,B", [(128256, 4), (1000, 3), (32000, 16)])
+def test_sample_topk_topp_vs_oracle(V, B):
+    """Full vocabulary sizes against the CPU restatement: identical tokens unless the two best scores are
+    within 1e-5 of each other; masks checked through draws that would expose a wrongly kept token
+    (noise tiny on one dropped token)."""
+    rng = np.random.default_rng(V + B)
+    logits = (rng.standard_normal((B, V)) * 3).astype(np.float32)
+    logits[0, : V // 7] = -np.inf
+    temp = rng.uniform(0.3, 2.0, B).astype(np.float32)
+    k = rng.integers(1, min(V, 2000), B).astype(np.int32)
+    k[-1] = V                                   # no top-k on the last row
+    p = rng.uniform(0.05, 1.0, B).astype(np.float32)
+    p[0] = 1.0                                  # no top-p on the first
+    noise = rng.exponential(1.0, (B, V)).astype(np.float32) + 1e-10
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(a).to(dev)
+    got = ops.sample_topk_topp(t(logits), t(temp), t(k), t(p), t(noise)).cpu().numpy()
+    want = orc.sample_topk_topp(logits, temp, k, p, noise)
+    scaled = logits / temp[:, None]
+    masked = orc.top_k_top_p_mask(scaled, k, p)
+    e = np.exp(masked - masked.max(axis=1, keepdims=True))
+    score = e / e.sum(axis=1, keepdims=True) / noise
+    for b in range(B):
+        if got[b] != want[b]:
+            assert score[b, got[b]] >= score[b, want[b]] * (1 - 1e-5), (b, got[b], want[b])
+    # a dropped token with vanishing noise would win the arg-max if a mask let it through
+    for b in range(B):
+        dropped = np.flatnonzero(~_kept(masked[b]) & np.isfinite(scaled[b]))
+        if dropped.size == 0:
+            continue
+        j = dropped[np.argmax(scaled[b][dropped])]      # the largest dropped logit: the first a loose threshold would admit
+        n2 = noise.copy()
+        n2[b, j] = 1e-30
+        got2 = ops.sample_topk_topp(t(logits), t(temp), t(k), t(p), t(n2)).cpu().numpy()
+        assert got2[b] != j, (b, j)
+    # only the top-k: k = 1 is the arg-max whatever the noise
+    one = ops.sample_topk_topp(t(logits), None, t(np.ones(B, dtype=np.int32)), None, t(noise)).cpu().numpy()
+    assert np.array_equal(one, np.argmax(logits, axis=1))

@@ -231,3 +231,17 @@ def test_moe_wna16_expert_path(golden):
         for rw in (True, False):   # bf16-rounded weights (what torch_moe multiplies) and fp32 weights (the kernels)
             out = f32(moe_ref.moe(g[tag + "_a"], w1, w2, w, ids, G, round_weight=rw))
             np.testing.assert_allclose(out, ref, rtol=0, atol=2e-2, err_msg=f"{tag} round_weight={rw}")
+
+
+def test_top_k_top_p_sampling_matches_the_reference_functions(golden):
+    """tests/golden/sampler_topk_topp.npz holds inputs and outputs of the reference's
+    apply_top_k_top_p_pytorch and random_sample (run on CPU with seeded generators)."""
+    d = golden("sampler_topk_topp")
+    scaled = d["logits"] / d["temperature"][:, None]
+    masked = orc.top_k_top_p_mask(scaled, d["top_k"], d["top_p"])
+    # same kept set, same values: the masks are thresholds, so this is exact unless the cumulative sum
+    # lands within rounding of 1 - p (then one boundary token may differ)
+    diff = (np.isneginf(masked) != np.isneginf(d["masked"])).sum(axis=1)
+    assert np.all(diff <= 1), diff
+    ids = orc.sample_topk_topp(d["logits"], d["temperature"], d["top_k"], d["top_p"], d["noise"])
+    assert np.array_equal(ids, d["ids"])

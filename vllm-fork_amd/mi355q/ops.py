@@ -821,6 +821,35 @@ def argmax(logits: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tenso
     return ids
 
 
+def sample_topk_topp(logits: torch.Tensor, temperature: torch.Tensor | None, top_k: torch.Tensor | None,
+                     top_p: torch.Tensor | None, noise: torch.Tensor) -> torch.Tensor:
+    """argmax(softmax(top_k_top_p_mask(logits / temperature)) / noise) per row, without sorting the vocabulary.
+    Stands in for apply_top_k_top_p + random_sample (vllm/v1/sample/ops/topk_topp_sampler.py:349-407, 441-466);
+    `noise` holds the Exp(1) draws the caller made with the request generators.  fp32 logits [rows, vocab]."""
+    _need_cuda(logits, noise)
+    if logits.dim() != 2 or logits.stride(1) != 1 or logits.dtype != torch.float32:
+        raise RuntimeError("sample_topk_topp: logits must be fp32 [rows, vocab] with a contiguous last dim")
+    B, V = logits.shape
+    if noise.shape != (B, V) or noise.dtype != torch.float32 or not noise.is_contiguous():
+        raise RuntimeError("sample_topk_topp: noise must be a contiguous fp32 tensor of the logits' shape")
+
+    def per_row(t, dtype, what):
+        if t is None:
+            return None
+        _need_cuda(t)
+        t = t.to(dtype).contiguous()
+        if t.shape != (B,):
+            raise RuntimeError(f"sample_topk_topp: {what} must have one entry per row")
+        return t
+    temperature = per_row(temperature, torch.float32, "temperature")
+    top_k = per_row(top_k, torch.int32, "top_k")
+    top_p = per_row(top_p, torch.float32, "top_p")
+    ids = torch.empty((B,), dtype=torch.int64, device=logits.device)
+    check(_lib.lib().mi355q_sample_topk_topp(logits.data_ptr(), logits.stride(0), _ptr(temperature), _ptr(top_k), _ptr(top_p),
+                                             noise.data_ptr(), ids.data_ptr(), B, V, _stream()))
+    return ids
+
+
 def apply_repetition_penalties(logits, prompt_mask, output_mask, repetition_penalties) -> None:
     """ops.apply_repetition_penalties (vllm/_custom_ops.py:336-357): in place."""
     _need_cuda(logits, prompt_mask, output_mask, repetition_penalties)

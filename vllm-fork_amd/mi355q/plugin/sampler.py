@@ -4,8 +4,9 @@ Mirrors vllm/v1/sample/sampler.py:72-149,228-302: logits are promoted to fp32, r
 penalties applied (vllm/_custom_ops.py:309-357), greedy rows take the first arg-max, random rows
 are temperature-scaled, top-k/top-p masked (ops/topk_topp_sampler.py:349-472: keep the k largest;
 then drop the lowest-probability tokens whose cumulative mass stays <= 1 - p, always keeping the
-top one) and sampled as argmax(softmax / Exp(1) noise) (:77-212).  Arg-max and the penalties
-run in HIP; the mask arithmetic for random rows is plain torch.
+top one) and sampled as argmax(softmax / Exp(1) noise) (:77-212).  Arg-max, the penalties and the
+random rows (temperature, both masks, softmax / noise arg-max: ops.sample_topk_topp) run in HIP; the
+torch formulation below serves CPU tensors.
 """
 from dataclasses import dataclass, field
 
@@ -51,13 +52,18 @@ def apply_top_k_top_p(logits: torch.Tensor, k: torch.Tensor | None, p: torch.Ten
     return logits.scatter_(1, idx, srt)
 
 
-def random_sample(probs: torch.Tensor, generators: dict[int, torch.Generator]) -> torch.Tensor:
-    q = torch.empty_like(probs)
-    if len(generators) != probs.shape[0]:
+def exponential_noise(like: torch.Tensor, generators: dict[int, torch.Generator]) -> torch.Tensor:
+    """Exp(1) draws, rows with their own generator overwritten from it (topk_topp_sampler.py:452-465)."""
+    q = torch.empty_like(like, dtype=torch.float32)
+    if len(generators) != like.shape[0]:
         q.exponential_()
     for i, g in generators.items():
         q[i].exponential_(generator=g)
-    return probs.div_(q).argmax(dim=-1).view(-1)
+    return q
+
+
+def random_sample(probs: torch.Tensor, generators: dict[int, torch.Generator]) -> torch.Tensor:
+    return probs.div_(exponential_noise(probs, generators)).argmax(dim=-1).view(-1)
 
 
 class Sampler(torch.nn.Module):
@@ -76,9 +82,13 @@ class Sampler(torch.nn.Module):
         temp = md.temperature
         if not md.all_random:
             temp = torch.where(temp < _SAMPLING_EPS, 1.0, temp)
-        logits = logits.div_(temp.unsqueeze(1))
-        logits = apply_top_k_top_p(logits, md.top_k, md.top_p)
-        sampled = random_sample(logits.softmax(dim=-1, dtype=torch.float32), md.generators)
+        if logits.is_cuda:
+            # one HIP kernel: temperature, both masks by radix selection, softmax / noise arg-max
+            sampled = ops.sample_topk_topp(logits.contiguous(), temp, md.top_k, md.top_p, exponential_noise(logits, md.generators))
+        else:
+            logits = logits.div_(temp.unsqueeze(1))
+            logits = apply_top_k_top_p(logits, md.top_k, md.top_p)
+            sampled = random_sample(logits.softmax(dim=-1, dtype=torch.float32), md.generators)
         if greedy is not None:
             sampled = torch.where(md.temperature < _SAMPLING_EPS, greedy, sampled)
         return SamplerOutput(sampled.to(torch.int32).unsqueeze(-1))
