@@ -17,6 +17,7 @@ from .. import ops
 from .awq import AutoAWQConfig
 from .gptq import AutoGPTQConfig
 from .linear import LinearBase, UnquantizedLinearMethod
+from . import parallel
 from .parallel import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
                        tensor_model_parallel_all_reduce)
 from .registry import QuantizationConfig, QuantizeMethodBase, register_quantization_config
@@ -278,6 +279,40 @@ def fused_experts(x: torch.Tensor, w13: ops.PackedMoeW4, w2: ops.PackedMoeW4, to
     return out
 
 
+class AgRsAll2AllManager:
+    """dispatch = all-gather of (hidden_states, topk_weights, topk_ids) over the expert-parallel ranks,
+    combine = reduce-scatter of the partial expert outputs
+    (vllm/distributed/device_communicators/all2all.py:44-153)."""
+
+    def __init__(self, sizes: list[int] | None = None):
+        self.sizes = sizes    # tokens per rank; None: every rank holds as many as this one
+
+    def _sizes(self, local_tokens: int) -> list[int]:
+        return self.sizes if self.sizes is not None else [local_tokens] * parallel.get_ep_world_size()
+
+    def dispatch(self, hidden_states, topk_weights, topk_ids):
+        sizes = self._sizes(hidden_states.shape[0])
+        if sizes[parallel.get_ep_rank()] != hidden_states.shape[0]:
+            raise ValueError("dispatch: this rank's token count differs from its entry in sizes")
+        return tuple(parallel.all_gatherv([hidden_states, topk_weights, topk_ids], sizes))
+
+    def combine(self, hidden_states):
+        n = parallel.get_ep_world_size()
+        sizes = self.sizes if self.sizes is not None else [hidden_states.shape[0] // n] * n
+        return parallel.reduce_scatterv(hidden_states, sizes)
+
+
+def expert_map_for_rank(num_experts: int, ep_rank: int, ep_size: int) -> torch.Tensor:
+    """Linear placement (fused_moe/layer.py determine_expert_map): rank r holds a contiguous run of
+    experts, the first num_experts % ep_size ranks one more; others map to -1."""
+    base, extra = divmod(num_experts, ep_size)
+    count = base + (1 if ep_rank < extra else 0)
+    start = ep_rank * base + min(ep_rank, extra)
+    m = torch.full((num_experts,), -1, dtype=torch.int32)
+    m[start:start + count] = torch.arange(count, dtype=torch.int32)
+    return m
+
+
 class FusedMoE(torch.nn.Module):
     """Routed experts of one decoder layer (fused_moe/layer.py `FusedMoE`): weights sharded over
     the intermediate dimension under tensor parallelism, optional expert_map for expert
@@ -315,8 +350,16 @@ class FusedMoE(torch.nn.Module):
     def process_weights_after_loading(self) -> None:
         self.quant_method.process_weights_after_loading(self)
 
-    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor,
+                tokens_per_rank: list[int] | None = None) -> torch.Tensor:
+        """With expert parallelism (parallel.init_expert_parallel, an expert_map from expert_map_for_rank)
+        the routed tokens of all ranks are exchanged around the local experts; `tokens_per_rank` gives the
+        ranks' token counts when they differ."""
         w, ids = fused_topk(router_logits, self.top_k, self.renormalize)
+        if parallel.get_ep_world_size() > 1 and self.expert_map is not None:
+            a2a = AgRsAll2AllManager(tokens_per_rank)
+            hs, w_all, ids_all = a2a.dispatch(hidden_states, w, ids)
+            return a2a.combine(self.quant_method.apply(self, hs, w_all, ids_all))
         out = self.quant_method.apply(self, hidden_states, w, ids)
         if self.reduce_results and self.tp_size > 1:
             out = tensor_model_parallel_all_reduce(out)
