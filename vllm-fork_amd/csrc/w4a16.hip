@@ -1726,6 +1726,188 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 1) void w4a16_mm_kernel(const Mm
   }
 }
 
+// ---------------------------------------------------------------------------
+// 17..32 rows per pass (decode batches), one workgroup per strip: the weights of a strip are streamed
+// ONCE, by eight waves that split K, exactly as the decode kernel above streams them -- the tiled
+// kernel re-reads every strip per 32-row block and needs K-slices plus a second kernel to fill the
+// chip, which costs 2-3x the streaming time at these sizes.  The activation rows do not fit in LDS
+// (32 rows x K), so every lane reads its own MFMA operand fragments straight from global memory (L2
+// resident: M x K x 2 bytes), one chunk ahead.  The per-chunk fp32 results tot += s (acc - (bias + z)
+// acc1) are accumulated in the wave's own slice of LDS instead of registers (two accumulator sets per
+// row tile do not fit beside the weight ring and the activation fragments at two waves per SIMD); the
+// slices are summed across waves at the end.  Same arithmetic and rounding as the other kernels.
+// ---------------------------------------------------------------------------
+template <typename DT, int NS, int CPW, bool HAS_ZC>
+__global__ __launch_bounds__(512) void w4a16_stream_rows_kernel(const MmParams p, int bursts) {
+  constexpr int SW = 16 * NS, QW = 4 * NS, RT = 2, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [NW][32][SW]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kq = lane >> 4, ml = lane & 15;
+  const int strip = blockIdx.x, row0 = blockIdx.y * 32;
+  const int Mt = min(32, p.M - row0);
+  const int groups = p.chunks / p.gchunks;
+  const int cfirst = wave * CPW * bursts;     // this wave's chunks: [cfirst, cfirst + CPW * bursts)
+  const u32x4* wstrip = p.wp + (size_t)strip * p.chunks * NS * 64 + lane;
+  const uint16_t* xr[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) xr[rt] = p.x + (size_t)min(row0 + 16 * rt + ml, p.M - 1) * p.ldx + 8 * kq;
+  auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
+  auto hi = [](uint32_t u) { return DT::to_f32((uint16_t)(u >> 16)); };
+
+  u32x4 w[CPW][NS];
+  auto issue_chunk = [&](int burst, int i) {
+    const size_t c = (size_t)(cfirst + burst * CPW + i);
+#pragma unroll
+    for (int pl = 0; pl < NS; pl++) w[i][pl] = __builtin_nontemporal_load(wstrip + (c * NS + pl) * 64);
+  };
+  auto load_x = [&](int c, u32x4 (&xf)[4][RT]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) xf[ks][rt] = *reinterpret_cast<const u32x4*>(xr[rt] + (size_t)c * 128 + 32 * ks);
+  };
+  u32x4 xc[4][RT], xn[4][RT];
+  load_x(cfirst, xc);
+#pragma unroll
+  for (int i = 0; i < CPW; i++) issue_chunk(0, i);
+
+  const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
+  float* mine = red + (size_t)wave * 32 * SW + ml * SW + QW * kq;   // + 16 rt SW + 4 sub
+  const int last = cfirst + CPW * bursts - 1;
+  for (int burst = 0; burst < bursts; burst++) {
+#pragma unroll
+    for (int i = 0; i < CPW; i++) {
+      const int c = cfirst + burst * CPW + i;
+      // requests of this chunk's scales and of the next chunk's activation fragments (the last chunk
+      // re-requests itself: loads stay unconditional)
+      u32x2 sv[NS], zv[NS];
+      {
+        const int g = c / p.gchunks;
+#pragma unroll
+        for (int sub = 0; sub < NS; sub++) {
+          const size_t off = ((size_t)strip * groups + g) * SW + QW * kq + 4 * sub;
+          sv[sub] = *reinterpret_cast<const u32x2*>(p.scales + off);
+          if constexpr (HAS_ZC) zv[sub] = *reinterpret_cast<const u32x2*>(p.zc + off);
+        }
+      }
+      load_x(min(c + 1, last), xn);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[RT][NS], acc1[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) {
+        acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sub = 0; sub < NS; sub++) acc[rt][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) acc1[rt] = mfma16<DT>(ones, xc[ks][rt], acc1[rt]);
+#pragma unroll
+        for (int sub = 0; sub < NS; sub++) {
+          const int e = ks * NS + sub;
+          const u32x4 wf = dequant_frag<DT>(w[i][e >> 2][e & 3]);
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++) acc[rt][sub] = mfma16<DT>(wf, xc[ks][rt], acc[rt][sub]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // dequantised fragments of one k-step live at a time
+      }
+      // the slot just consumed is refilled at once
+      if (burst + 1 < bursts) issue_chunk(burst + 1, i);
+      // lane (kq, ml): rows 16 rt + ml, channels QW kq + 4 sub + r of the strip
+#pragma unroll
+      for (int sub = 0; sub < NS; sub++) {
+        f32x4 sc, zz;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          sc[r] = (r & 1) ? hi(sv[sub][r >> 1]) : lo(sv[sub][r >> 1]);
+          if constexpr (HAS_ZC) zz[r] = (r & 1) ? hi(zv[sub][r >> 1]) : lo(zv[sub][r >> 1]);
+          else zz[r] = DT::int4_bias + 8.0f;
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+          f32x4* dst = reinterpret_cast<f32x4*>(mine + 16 * rt * SW + 4 * sub);
+          f32x4 t = (burst == 0 && i == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : *dst;
+#pragma unroll
+          for (int r = 0; r < 4; r++) t[r] = __builtin_fmaf(sc[r], __builtin_fmaf(-zz[r], acc1[rt][r], acc[rt][sub][r]), t[r]);
+          *dst = t;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) xc[ks][rt] = xn[ks][rt];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < Mt * QW; it += 512) {
+    const int m_l = it / QW, nl = 4 * (it % QW);
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NW; i++) a += *reinterpret_cast<const f32x4*>(red + ((size_t)i * 32 + m_l) * SW + nl);
+    mm_store<DT>(p, row0 + m_l, strip * SW + nl, a);
+  }
+}
+
+// (NS, CPW) pairs the streaming rows kernel is built for
+static bool stream_rows_built(int ns, int cpw) {
+  switch (ns) {
+    case 1: return cpw == 1 || cpw == 2 || cpw == 4 || cpw == 7 || cpw == 8;
+    case 2: return cpw == 1 || cpw == 2 || cpw == 4;
+    case 4: return cpw == 1 || cpw == 2 || cpw == 4;
+    case 7: return cpw == 1 || cpw == 2;
+    default: return false;
+  }
+}
+
+struct StreamRowsPlan {
+  bool ok;
+  int ns, cpw, bursts;
+  size_t lds;
+};
+
+// rows 17..64 (two passes above 32), strips that alone occupy the chip, K that eight waves divide
+static StreamRowsPlan plan_stream_rows(int M, int N, int K, int G, int sw) {
+  StreamRowsPlan sp{false, 0, 0, 0, 0};
+  static const int max_rows = env_int("MI355Q_STREAM_ROWS_MAX", 64);
+  if (M < 17 || M > max_rows || G % 128 || K % 128 || sw % 16 || N % sw) return sp;
+  const int ns = sw / 16, chunks = K / 128;
+  // Every workgroup reads all M x K activations, so the activation traffic is (N / sw) x M x K x 2 bytes:
+  // on 16-wide strips that is 8x the weights at 32 rows (measured: down_proj 14336x4096 31 us against 21 us
+  // for the tiled kernel with its K-slice merge, o_proj 12.4 + norm against 7.4 + merge-and-norm 6) -- the
+  // tiled kernel shares one activation tile between 256 channels and keeps those layers.  On 32- and
+  // 112-wide strips streaming wins (qkv 12.7 against 11.7 + 6.4, gate_up 23.5 against 23.2 + 5.6).
+  static const int min_ns = env_int("MI355Q_STREAM_ROWS_MIN_NS", 2);
+  if (ns < min_ns || chunks % 8 || (long)(N / sw) < 64) return sp;
+  const int per = chunks / 8;
+  const int cands[5] = {8, 7, 4, 2, 1};
+  for (int cpw : cands) {
+    if (per % cpw || cpw * ns > 16 || !stream_rows_built(ns, cpw)) continue;
+    sp.ok = true; sp.ns = ns; sp.cpw = cpw; sp.bursts = per / cpw;
+    sp.lds = (size_t)8 * 32 * sw * sizeof(float);
+    return sp;
+  }
+  return sp;
+}
+
+template <typename DT>
+static int launch_stream_rows(const MmParams& p, const StreamRowsPlan& sp, hipStream_t stream) {
+  dim3 grid(p.N / (16 * sp.ns), (p.M + 31) / 32), block(512);
+#define MI355Q_SR(NS_, CPW_)                                                                                             \
+  if (sp.ns == NS_ && sp.cpw == CPW_) {                                                                                  \
+    if (p.zc) hipLaunchKernelGGL((w4a16_stream_rows_kernel<DT, NS_, CPW_, true>), grid, block, sp.lds, stream, p, sp.bursts);  \
+    else hipLaunchKernelGGL((w4a16_stream_rows_kernel<DT, NS_, CPW_, false>), grid, block, sp.lds, stream, p, sp.bursts);      \
+    return check_launch("w4a16_stream_rows_kernel");                                                                     \
+  }
+  MI355Q_SR(1, 1) MI355Q_SR(1, 2) MI355Q_SR(1, 4) MI355Q_SR(1, 7) MI355Q_SR(1, 8)
+  MI355Q_SR(2, 1) MI355Q_SR(2, 2) MI355Q_SR(2, 4)
+  MI355Q_SR(4, 1) MI355Q_SR(4, 2) MI355Q_SR(4, 4)
+  MI355Q_SR(7, 1) MI355Q_SR(7, 2)
+#undef MI355Q_SR
+  return set_error(MI355Q_EINVAL, "w4a16_stream_rows: no kernel for %d subtiles x %d chunks", sp.ns, sp.cpw);
+}
+
 template <typename DT>
 __global__ __launch_bounds__(256) void w4a16_mm_reduce_kernel(const MmParams p) {
   const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;   // 4 consecutive channels of one row
@@ -2151,15 +2333,22 @@ extern "C" int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const
                      ((uintptr_t)c & 7) == 0 && ((uintptr_t)zc & 15) == 0 && ((uintptr_t)bias & 7) == 0,
                  "w4a16_mm: pointers must be 16-byte aligned");
   MI355Q_REQUIRE(!silu_pairs || bias == nullptr, "w4a16_mm: the SiLU-pair epilogue takes no bias");
-  const MmPlan mp = plan_mm(M, N, K, G, tile);
-  MI355Q_REQUIRE(mp.ok, "w4a16_mm: needs a group size that is a multiple of 128 and N a multiple of %d for strip width %d",
-                 tile == 112 ? 448 : 256, tile);
   MmParams p;
   p.x = (const uint16_t*)a; p.ldx = lda; p.wp = (const u32x4*)packed;
   p.scales = (const uint16_t*)scales; p.zc = (const uint16_t*)zc; p.bias = (const uint16_t*)bias;
   p.out = (uint16_t*)c; p.partial = nullptr;
   p.M = M; p.N = N; p.K = K; p.chunks = K / 128; p.gchunks = G / 128;
-  p.splits = mp.splits; p.cps = p.chunks / mp.splits; p.epi_silu = silu_pairs ? 1 : 0;
+  p.epi_silu = silu_pairs ? 1 : 0;
+  // decode batches of 17..64 rows: stream every strip once
+  if (const StreamRowsPlan sp = plan_stream_rows(M, N, K, G, tile); sp.ok) {
+    p.splits = 1; p.cps = p.chunks;
+    return act_dtype == MI355Q_BF16 ? launch_stream_rows<BF16>(p, sp, (hipStream_t)stream)
+                                    : launch_stream_rows<FP16>(p, sp, (hipStream_t)stream);
+  }
+  const MmPlan mp = plan_mm(M, N, K, G, tile);
+  MI355Q_REQUIRE(mp.ok, "w4a16_mm: needs a group size that is a multiple of 128 and N a multiple of %d for strip width %d",
+                 tile == 112 ? 448 : 256, tile);
+  p.splits = mp.splits; p.cps = p.chunks / mp.splits;
   if (mp.splits > 1) {
     MI355Q_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "w4a16_mm: K-slices need a 16-byte aligned workspace");
     if (workspace_bytes < mp.ws) return set_error(MI355Q_ENOSPACE, "w4a16_mm: workspace %zu B < %zu B", workspace_bytes, mp.ws);
@@ -2233,15 +2422,23 @@ extern "C" int mi355q_w4a16_mm_add_rms_norm(const void* a, int lda, const void* 
     if (e) return e;
     return mi355q_splitk_add_rms_norm(out, residual, r.partial, rp.splits, bias, norm_weight, epsilon, M, N, act_dtype, stream);
   }
-  const MmPlan mp = plan_mm(M, N, K, G, tile);
-  MI355Q_REQUIRE(mp.ok, "w4a16_mm_add_rms_norm: needs a group size that is a multiple of 128 and N a multiple of %d for strip width %d",
-                 tile == 112 ? 448 : 256, tile);
   MmParams p;
   p.x = (const uint16_t*)a; p.ldx = lda; p.wp = (const u32x4*)packed;
   p.scales = (const uint16_t*)scales; p.zc = (const uint16_t*)zc; p.bias = (const uint16_t*)bias;
   p.out = (uint16_t*)out; p.partial = nullptr;
   p.M = M; p.N = N; p.K = K; p.chunks = K / 128; p.gchunks = G / 128;
-  p.splits = mp.splits; p.cps = p.chunks / mp.splits; p.epi_silu = 0;
+  p.epi_silu = 0;
+  if (const StreamRowsPlan sp = plan_stream_rows(M, N, K, G, tile); sp.ok) {
+    p.splits = 1; p.cps = p.chunks;
+    const int e = act_dtype == MI355Q_BF16 ? launch_stream_rows<BF16>(p, sp, (hipStream_t)stream)
+                                           : launch_stream_rows<FP16>(p, sp, (hipStream_t)stream);
+    if (e) return e;
+    return mi355q_fused_add_rms_norm(out, N, residual, norm_weight, epsilon, M, N, act_dtype, stream);
+  }
+  const MmPlan mp = plan_mm(M, N, K, G, tile);
+  MI355Q_REQUIRE(mp.ok, "w4a16_mm_add_rms_norm: needs a group size that is a multiple of 128 and N a multiple of %d for strip width %d",
+                 tile == 112 ? 448 : 256, tile);
+  p.splits = mp.splits; p.cps = p.chunks / mp.splits;
   if (mp.splits > 1) {
     MI355Q_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "w4a16_mm_add_rms_norm: K-slices need a 16-byte aligned workspace");
     if (workspace_bytes < mp.ws) return set_error(MI355Q_ENOSPACE, "w4a16_mm_add_rms_norm: workspace %zu B < %zu B", workspace_bytes, mp.ws);
