@@ -93,6 +93,19 @@ int mi355q_w4a16_choose_tile(int K, int N, int G);
  */
 int mi355q_w4a16_choose_strip(int K, int N, int G);
 
+/* 2- and 3-bit GPTQ tensors -> the 4-bit checkpoint layout mi355q_w4a16_repack takes (device, load time).
+ *   axis 0: src int32 [values * bits / 32, other], one bit string per column along K (qweight)
+ *           -> dst int32 [values / 8, other], nibble j of word r = value 8 r + j
+ *   axis 1: src int32 [other, values * bits / 32], one bit string per row along N (qzeros)
+ *           -> dst int32 [other, values / 8]
+ * Value i occupies bits [bits i, bits i + bits) of its string (32-bit words in order); `add` is added to
+ * every value (symmetric weights: 8 - 2^(bits-1), so that the kernels' constant zero point 8 applies).
+ * Replaces the 2- / 3-bit branches of gptq_shuffle + gptq_gemm
+ * (csrc/libtorch_stable/quantization/gptq/q_gemm.cu:323-682, qdq_2.cuh, qdq_3.cuh): the widened
+ * weights run on the W4A16 kernels. */
+int mi355q_gptq_expand_bits(const void* src, void* dst, int values, int other, int bits, int add, int axis,
+                            mi355q_stream_t stream);
+
 /*
  * Load-time repack of a 4-bit checkpoint tensor into the kernel's tiled layout
  * (1 KiB tiles of `tile` output channels x 2048/tile input channels, tiles of one

@@ -109,6 +109,46 @@ def unpack_cols(p, awq_order=False):
 
 
 # ---- W4A16 -------------------------------------------------------------
+def gptq_pack_bits(q, bits, axis=0):
+    """AutoGPTQ packing of b-bit values (b = 2, 3, 4, 8): one little-endian bit string per column along
+    K (axis 0: qweight [K * b / 32, N]) or per row along N (axis 1: qzeros [K/G, N * b / 32]); value i at
+    bits [b i, b i + b).  For b = 3 this is the 32-values-in-3-words layout drawn in
+    csrc/libtorch_stable/quantization/gptq/qdq_3.cuh:21-23; for b = 4 it equals gptq_pack."""
+    q = np.asarray(q, dtype=np.uint64)
+    if axis == 1:
+        return np.ascontiguousarray(gptq_pack_bits(q.T, bits, 0).T)
+    K, N = q.shape
+    assert (K * bits) % 32 == 0
+    out = np.zeros((K * bits // 32, N), dtype=np.uint64)
+    for k in range(K):
+        bit = k * bits
+        w, sh = bit // 32, bit % 32
+        v = q[k] << np.uint64(sh)
+        out[w] |= v & np.uint64(0xffffffff)
+        if sh + bits > 32:
+            out[w + 1] |= v >> np.uint64(32)
+    return out.astype(np.uint32).view(np.int32)
+
+
+def gptq_unpack_bits(p, bits, axis=0):
+    """Inverse of gptq_pack_bits: int32 values in [0, 2^bits)."""
+    p = np.asarray(p).view(np.uint32).astype(np.uint64)
+    if axis == 1:
+        return np.ascontiguousarray(gptq_unpack_bits(p.T.astype(np.uint32).view(np.int32), bits, 0).T)
+    W, N = p.shape
+    K = W * 32 // bits
+    q = np.zeros((K, N), dtype=np.int32)
+    mask = np.uint64((1 << bits) - 1)
+    for k in range(K):
+        bit = k * bits
+        w, sh = bit // 32, bit % 32
+        v = p[w] >> np.uint64(sh)
+        if sh + bits > 32:
+            v |= p[w + 1] << np.uint64(32 - sh)
+        q[k] = (v & mask).astype(np.int32)
+    return q
+
+
 def _wshape(qw, layout):
     if layout == W_GPTQ:
         return qw.shape[0] * 8, qw.shape[1]

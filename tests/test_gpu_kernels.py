@@ -1282,3 +1282,36 @@ def test_w4a16_stream_rows_vs_oracle(M, K, N, G, tile, awq, dt, silu):
     assert bad.mean() < 1e-5
     assert (to_bits(out) == ref).mean() > (0.9 if dt == orc.FP16 or silu else 0.97)
     assert torch.equal(out, ops.w4a16_mm(to_dev(a, dt), w, bias=None if bias is None else to_dev(bias, dt), silu_pairs=silu))
+
+
+# ---- 2- and 3-bit GPTQ ---------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,sym,v2,M,K,N,G", [(2, True, False, 1, 4096, 4096, 128), (3, True, False, 3, 2048, 6144, 128),
+                                                 (3, False, False, 1, 4096, 4096, 64), (2, False, True, 20, 1024, 4096, 128),
+                                                 (3, False, True, 200, 1024, 2048, 128)])
+def test_gptq_2_and_3_bit_checkpoints(bits, sym, v2, M, K, N, G):
+    """2- / 3-bit AutoGPTQ tensors widened to the 4-bit layout at load time (mi355q_gptq_expand_bits) and
+    run on the W4A16 kernels: bit-exact widening against the oracle's bit-string unpacker, and the GEMM
+    against the oracle on the same values -- W[k, n] = (q - z) * s with z = 2^(bits-1) for symmetric
+    checkpoints, stored as z - 1 unless use_v2_format (q_gemm.cu:202,323-682)."""
+    rng = np.random.default_rng(bits * 1000 + K + N + M)
+    q = rng.integers(0, 1 << bits, size=(K, N), dtype=np.int32)
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N)) + 0.01).astype(np.float32))
+    a = orc.f32_to_h16(0.25 * rng.standard_normal((M, K)).astype(np.float32))
+    qw = orc.gptq_pack_bits(q, bits)
+    wide = ops.gptq_expand_bits(i32(qw), bits, add=3, axis=0)
+    assert np.array_equal(wide.cpu().numpy(), orc.gptq_pack(q + 3))
+    if sym:
+        w = ops.gptq_repack(i32(qw), to_dev(s), None, G, bits=bits)
+        ref = orc.w4a16_gemm(a, orc.gptq_pack(q + 8 - (1 << (bits - 1))), s, None, None, G=G)
+    else:
+        z = rng.integers(1, 1 << bits, size=(K // G, N), dtype=np.int32)          # true zero points
+        stored = z if v2 else z - 1
+        qz = orc.gptq_pack_bits(stored, bits, axis=1)
+        assert np.array_equal(ops.gptq_expand_bits(i32(qz), bits, add=0, axis=1).cpu().numpy(), orc.pack_cols(stored))
+        w = ops.gptq_repack(i32(qw), to_dev(s), i32(qz), G, bits=bits, use_v2_format=v2)
+        ref = orc.w4a16_gemm(a, orc.gptq_pack(q), s, orc.pack_cols(z), None, G=G, zp_mode=orc.ZP_NSEQ)
+    out = ops.gptq_gemm(to_dev(a), w, None, None, None, True, v2, bits)
+    got, want = f32(to_bits(out)), f32(ref)
+    assert np.allclose(got, want, rtol=1e-2, atol=1e-2)
+    assert (to_bits(out) == ref).mean() > 0.97

@@ -245,3 +245,25 @@ def test_top_k_top_p_sampling_matches_the_reference_functions(golden):
     assert np.all(diff <= 1), diff
     ids = orc.sample_topk_topp(d["logits"], d["temperature"], d["top_k"], d["top_p"], d["noise"])
     assert np.array_equal(ids, d["ids"])
+
+
+def test_gptq_bit_strings_of_2_and_3_bit_checkpoints():
+    """AutoGPTQ's b-bit packing as the reference's kernels read it: for 3 bits the word picture of
+    csrc/libtorch_stable/quantization/gptq/qdq_3.cuh:21-23 (qa: values 0-9 + low two bits of value 10;
+    qb: its high bit, values 11-20, low bit of 21; qc: its high two bits, values 22-31); 4 bits equal the
+    golden gptq_pack.  Parity of the 2- / 3-bit GEMM itself is unpinned by reference fixtures (its tests
+    only opcheck gptq_gemm): the widened weights are checked against the 4-bit oracle."""
+    rng = np.random.default_rng(0)
+    for b in (2, 3, 4, 8):
+        q = rng.integers(0, 1 << b, size=(64, 5), dtype=np.int32)
+        assert np.array_equal(orc.gptq_unpack_bits(orc.gptq_pack_bits(q, b), b), q)
+        z = rng.integers(0, 1 << b, size=(3, 64), dtype=np.int32)
+        assert np.array_equal(orc.gptq_unpack_bits(orc.gptq_pack_bits(z, b, 1), b, 1), z)
+    q = rng.integers(0, 16, size=(64, 8), dtype=np.int32)
+    assert np.array_equal(orc.gptq_pack_bits(q, 4), orc.gptq_pack(q))
+    vals = [int(v) for v in rng.integers(0, 8, size=32)]
+    qa, qb, qc = (int(w) for w in orc.gptq_pack_bits(np.array(vals, dtype=np.int32).reshape(32, 1), 3).view(np.uint32)[:, 0])
+    assert all(((qa >> (3 * i)) & 7) == vals[i] for i in range(10)) and (qa >> 30) == (vals[10] & 3)
+    assert (qb & 1) == (vals[10] >> 2) and all(((qb >> (1 + 3 * i)) & 7) == vals[11 + i] for i in range(10))
+    assert (qb >> 31) == (vals[21] & 1) and (qc & 3) == (vals[21] >> 1)
+    assert all(((qc >> (2 + 3 * i)) & 7) == vals[22 + i] for i in range(10))

@@ -2302,6 +2302,50 @@ extern "C" int mi355q_w4a16_gate_up_silu_supported(int K, int N, int G, int tile
   return plan_burst(1, K, G, tile / 16, false).ok ? 1 : 0;
 }
 
+/* ---- 2- and 3-bit GPTQ checkpoints ---------------------------------------------------
+ * AutoGPTQ packs b-bit values as one little-endian bit string per column (weights, along K) or per row
+ * (zero points, along N): value i sits at bits [b i, b i + b) of the string, 32-bit words in order -- for
+ * b = 3 that is the 32-values-in-3-words layout of qdq_3.cuh:21-23.  The values are widened to the 4-bit
+ * layout the kernels read (plus `add`), so these checkpoints run on the W4A16 path unchanged: symmetric
+ * weights use add = 8 - 2^(b-1) with the constant zero point 8, zero-point checkpoints add = 0. */
+namespace mi355q {
+__global__ void gptq_expand_bits_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int out_rows,
+                                        int out_cols, int src_cols, int bits, int add, int axis) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)out_rows * out_cols) return;
+  const int r = (int)(idx / out_cols), c = (int)(idx - (long)r * out_cols);
+  const uint32_t mask = (1u << bits) - 1u;
+  uint32_t out = 0u;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    // value index along the packed axis, its place in the source bit string
+    const long v = axis == 0 ? (long)r * 8 + j : (long)c * 8 + j;
+    const long bit = v * bits;
+    const int word = (int)(bit >> 5), sh = (int)(bit & 31);
+    const size_t at = axis == 0 ? (size_t)word * src_cols + c : (size_t)r * src_cols + word;
+    uint32_t val = src[at] >> sh;
+    if (sh + bits > 32) val |= src[axis == 0 ? at + src_cols : at + 1] << (32 - sh);
+    out |= (((val & mask) + (uint32_t)add) & 0xfu) << (4 * j);
+  }
+  dst[idx] = out;
+}
+}  // namespace mi355q
+
+extern "C" int mi355q_gptq_expand_bits(const void* src, void* dst, int values, int other, int bits, int add, int axis,
+                                       mi355q_stream_t stream) {
+  MI355Q_REQUIRE(src && dst, "gptq_expand_bits: null pointer");
+  MI355Q_REQUIRE(bits == 2 || bits == 3, "gptq_expand_bits: %d-bit values (2 or 3 expected; 4 needs no widening)", bits);
+  MI355Q_REQUIRE(axis == 0 || axis == 1, "gptq_expand_bits: axis %d", axis);
+  MI355Q_REQUIRE(values > 0 && other > 0 && values % 32 == 0, "gptq_expand_bits: %d values along the packed axis (multiple of 32 expected)", values);
+  MI355Q_REQUIRE(add >= 0 && add + (1 << bits) - 1 <= 15, "gptq_expand_bits: add = %d leaves the nibble", add);
+  const int out_rows = axis == 0 ? values / 8 : other, out_cols = axis == 0 ? other : values / 8;
+  const int src_cols = axis == 0 ? other : values * bits / 32;
+  const long n = (long)out_rows * out_cols;
+  hipLaunchKernelGGL(gptq_expand_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint32_t*)src, (uint32_t*)dst, out_rows, out_cols, src_cols, bits, add, axis);
+  return check_launch("gptq_expand_bits_kernel");
+}
+
 /* Diagnostics: when set, every burst-kernel workgroup writes four 100 MHz timestamps (entry,
  * activations staged, weights consumed, done) at stamps[4 * strip ..].  Not part of the public ABI. */
 extern "C" void mi355q_debug_burst_stamps(void* stamps) { g_burst_stamps = (unsigned long long*)stamps; }

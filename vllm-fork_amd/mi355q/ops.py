@@ -348,13 +348,43 @@ def w4a16_dequantize(w: PackedW4, out: torch.Tensor | None = None) -> torch.Tens
     return out
 
 
+def gptq_expand_bits(t: torch.Tensor, bits: int, add: int = 0, axis: int = 0) -> torch.Tensor:
+    """2- / 3-bit AutoGPTQ tensor (qweight: axis 0, bit strings along K; qzeros: axis 1, along N) -> the 4-bit
+    layout of the same values (+ add)."""
+    _need_cuda(t)
+    if t.dtype != torch.int32 or t.dim() != 2 or not t.is_contiguous():
+        raise RuntimeError("gptq_expand_bits: a contiguous 2-d int32 tensor is expected")
+    packed, other = (t.shape[0], t.shape[1]) if axis == 0 else (t.shape[1], t.shape[0])
+    if (packed * 32) % bits:
+        raise RuntimeError(f"gptq_expand_bits: {packed} words do not hold whole {bits}-bit values")
+    values = packed * 32 // bits
+    out = torch.empty((values // 8, other) if axis == 0 else (other, values // 8), dtype=torch.int32, device=t.device)
+    check(_lib.lib().mi355q_gptq_expand_bits(t.data_ptr(), out.data_ptr(), values, other, bits, add, axis, _stream()))
+    return out
+
+
+def gptq_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor | None, group_size: int, bits: int = 4,
+                use_v2_format: bool = False, tile: int = 0) -> PackedW4:
+    """What gptq_shuffle prepares for gptq_gemm (vllm/_custom_ops.py:558-583), for 2-, 3- and 4-bit AutoGPTQ
+    tensors: qweight int32 [K * bits / 32, N]; qzeros int32 [K/G, N * bits / 32] or None (symmetric: zero point
+    2^(bits-1)); stored zero points are z - 1 unless use_v2_format (q_gemm.cu:202)."""
+    if bits not in (2, 3, 4):
+        raise RuntimeError(f"gptq_repack: {bits}-bit weights (8 bits: gptq8_repack)")
+    zp_mode = _lib.ZP_CONST if qzeros is None else (_lib.ZP_NSEQ if use_v2_format else _lib.ZP_GPTQ_V1)
+    if bits != 4:
+        qweight = gptq_expand_bits(qweight, bits, add=(8 - (1 << (bits - 1))) if qzeros is None else 0, axis=0)
+        if qzeros is not None:
+            qzeros = gptq_expand_bits(qzeros, bits, add=0, axis=1)
+    return w4a16_repack(qweight, scales, qzeros, group_size, _lib.W_GPTQ, zp_mode, tile=tile)
+
+
 def gptq_gemm(a, b_q_weight: PackedW4, b_gptq_qzeros, b_gptq_scales, b_g_idx, use_exllama: bool,
               use_v2_format: bool, bit: int) -> torch.Tensor:
     """Signature of ops.gptq_gemm (vllm/_custom_ops.py:558-577).  b_q_weight is the
     repacked weight (the reference passes the gptq_shuffle'd tensor here); zeros and scales
     travel inside it; g_idx must be empty here -- checkpoints with activation reordering are served
     one level up (MI355XW4A16LinearKernel sorts the rows at load time and gathers the inputs)."""
-    if bit != 4:
+    if bit not in (2, 3, 4):   # 2 / 3 bits: b_q_weight comes from gptq_repack(bits=...), widened to the 4-bit layout
         raise RuntimeError(f"gptq_gemm: {bit}-bit weights go through wi8a16_gemm (8 bits) or are not supported")
     if b_g_idx is not None and b_g_idx.numel() > 0:
         raise RuntimeError("gptq_gemm: pass activation-reordered layers through MI355XW4A16LinearKernel (g_idx must be empty here)")
