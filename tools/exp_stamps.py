@@ -33,7 +33,7 @@ def run(name, K, N, pro):
     t0 = t[:, 0].min()
     t = (t - t0) / 100.0   # us
     q = lambda v: f"{v.min():5.2f}/{v.median():5.2f}/{v.max():5.2f}"
-    print(f"{name:10s} tile {ws[0].tile:3d} blocks {blocks}: start {q(t[:,0])} | scales in LDS (thread 0) {q(t[:,4])} | x staged (thread 0) {q(t[:,5])} | staged {q(t[:,1])} | consumed {q(t[:,2])} | done {q(t[:,3])}  (us after first start, min/med/max)")
+    print(f"{name:10s} tile {ws[0].tile:3d} blocks {blocks}: start {q(t[:,0])} | scales in LDS (thread 0) {q(t[:,4])} | x staged (thread 0) {q(t[:,5])} | own sum {q(t[:,6])} | all sums {q(t[:,7])} | staged {q(t[:,1])} | consumed {q(t[:,2])} | done {q(t[:,3])}  (us after first start, min/med/max)")
 shapes = [("gate_up", 4096, 28672, "norm"), ("gate_up_n", 4096, 28672, "none"), ("down", 14336, 4096, "silu"),
                         ("down_n", 14336, 4096, "none"), ("qkv", 4096, 6144, "norm"), ("o", 4096, 4096, "none")]
 if len(sys.argv) > 1 and sys.argv[1] == "tp8":   # Llama-3-70B per-rank shapes at TP = 8

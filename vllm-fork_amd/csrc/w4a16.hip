@@ -812,15 +812,19 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
   // reads above of workgroups dispatched a little later (dispatch skew is 0.3-0.7 us), the scales --
   // then waits behind megabytes of weights and arrives microseconds late, which holds back consumption
   // everywhere.  So: a short pause that lets the prologue reads of the late starters get out first,
-  // then one chunk per wave (NS KiB), and the rest of the ring after the prologue arithmetic, just in
-  // front of the barrier.  Measured on Llama-3-8B decode (tok/s): all at once 568, one chunk first 593,
-  // with the pause of 12 x 64 clocks 620, longer pauses (20, 30) 615 and 603, a wait for the prologue
-  // inputs instead of the pause 583.  The three macros are build-time knobs for such sweeps.
+  // then one chunk per wave (NS KiB), and the rest of the ring after the barrier that ends the prologue:
+  // a wave that asks for more than the CU's miss queue holds stalls AT THE ISSUE, and with the late
+  // requests in front of that barrier the whole workgroup waited ~1 us for its slowest issuer before
+  // consuming data that had long arrived (gate_up 14.7 -> 14.2 us).  Measured on Llama-3-8B decode
+  // (tok/s): all at once 568, one chunk first 593, with the pause of 12 x 64 clocks 620, longer pauses
+  // (20, 30) 615 and 603, a wait for the prologue inputs instead of the pause 583.  The macros are
+  // build-time knobs for such sweeps (MI355Q_BURST_LATE: 0 = rest right after the first planes' wait,
+  // 1 = in front of the barrier, 2 = behind it).
 #ifndef MI355Q_BURST_FP
 #define MI355Q_BURST_FP -1
 #endif
 #ifndef MI355Q_BURST_LATE
-#define MI355Q_BURST_LATE 1
+#define MI355Q_BURST_LATE 2
 #endif
 #ifndef MI355Q_BURST_DELAY
 #define MI355Q_BURST_DELAY 12
@@ -842,7 +846,7 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
   };
 #pragma unroll
   for (int f = 0; f < FP; f++) issue_plane(f);
-#if !MI355Q_BURST_LATE
+#if MI355Q_BURST_LATE == 0
   if constexpr (FP < RING) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FP) : "memory");
@@ -894,7 +898,9 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
       }
       ss = wave_sum(ss);
       if (lane == 0) red[wave] = ss;
+      if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
       __syncthreads();
+      if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
       float t = 0.f;
       for (int i = 0; i < nw; i++) t += red[i];
       const float rs = rsqrtf(t / (float)p.K + p.eps);
@@ -1012,11 +1018,15 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
     }
   }
   if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-#if MI355Q_BURST_LATE
+#if MI355Q_BURST_LATE == 1
 #pragma unroll
   for (int f = FP; f < RING; f++) issue_plane(f);
 #endif
   __syncthreads();
+#if MI355Q_BURST_LATE == 2
+#pragma unroll
+  for (int f = FP; f < RING; f++) issue_plane(f);
+#endif
   if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
   // ---- consume the weight planes in arrival order
