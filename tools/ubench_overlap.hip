@@ -73,6 +73,68 @@ __global__ __launch_bounds__(512, 2) void ovl_k(const u32x4* __restrict__ w, lon
   }
 }
 
+// The same chain as ONE persistent kernel per layer: every workgroup walks the stages; before it waits for
+// the previous stage's counter it has already requested the first DEPTH KiB per wave of its slice of this
+// stage's weights, so the memory system keeps streaming through the hand-off.  Dynamic LDS (unused) pins
+// one workgroup per CU.
+struct PStage { const u32x4* w; long vecs_per_wg; int wgs; };
+struct PLayer { PStage st[5]; const unsigned* x_in; unsigned* xbuf; unsigned* flags; unsigned* err; unsigned long long spin_limit; };
+
+template <int DEPTH>
+__global__ __launch_bounds__(512) void persist_k(const PLayer L) {
+  extern __shared__ unsigned pin_lds[];
+  __shared__ unsigned red[16];
+  __shared__ unsigned s_x[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int s = 0; s < 5; s++) {
+    const PStage st = L.st[s];
+    const bool active = (int)blockIdx.x < st.wgs;
+    const long per_wave = st.vecs_per_wg / nw;
+    const u32x4* p = st.w + (long)blockIdx.x * st.vecs_per_wg + (long)wave * per_wave + lane;
+    const long steps = per_wave / 64;
+    u32x4 buf[DEPTH];
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < DEPTH; i++) buf[i] = __builtin_nontemporal_load(p + (long)(i < steps ? i : 0) * 64);
+    }
+    const unsigned* xin = s == 0 ? L.x_in : L.xbuf + 256 * (s - 1);
+    if (s > 0) {
+      if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(L.flags + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)L.st[s - 1].wgs) {
+          __builtin_amdgcn_s_sleep(2);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > L.spin_limit) { *L.err = 1; break; }
+        }
+      }
+      __syncthreads();
+    }
+    if (!active) continue;      // uniform per workgroup; it still took part in the wait above
+    if (threadIdx.x < 256) s_x[threadIdx.x] = __hip_atomic_load(xin + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    unsigned acc = s_x[lane] ^ s_x[lane + 64] ^ s_x[lane + 128] ^ s_x[lane + 192];
+    for (long k = 0; k < steps; k += DEPTH) {
+#pragma unroll
+      for (int i = 0; i < DEPTH; i++) {
+        u32x4 v = buf[i];
+        if (k + i < steps) acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+        if (k + DEPTH + i < steps) buf[i] = __builtin_nontemporal_load(p + (k + DEPTH + i) * 64);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc ^= __shfl_xor(acc, o, 64);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned t = 0;
+      for (int i = 0; i < nw; i++) t ^= red[i];
+      __hip_atomic_store(L.xbuf + 256 * s + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(L.flags + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();   // red and s_x are reused by the next stage
+  }
+}
+
 struct Stage { double mb; int wgs; };
 
 // mode 0: one stream, no counters (stream order carries the dependency)
@@ -129,6 +191,51 @@ static float run(hipStream_t sa, hipStream_t sb, const u32x4* weights, size_t to
   return ms * 1000.f / (reps * layers);
 }
 
+template <int DEPTH>
+static float run_persist(hipStream_t sa, const u32x4* weights, size_t total_vecs, unsigned* xbuf, unsigned* flags, unsigned* err,
+                         const std::vector<Stage>& stages, int layers, double* checksum) {
+  hipGraph_t g; hipGraphExec_t ge;
+  hipFuncSetAttribute((const void*)persist_k<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  hipStreamBeginCapture(sa, hipStreamCaptureModeGlobal);
+  hipMemsetAsync(flags, 0, sizeof(unsigned) * 8 * layers, sa);
+  size_t off = 0;
+  for (int l = 0; l < layers; l++) {
+    PLayer L;
+    int maxw = 0;
+    for (int k = 0; k < 5; k++) {
+      long vpw = (long)(stages[k].mb * 1e6 / 16 / stages[k].wgs) / (8 * 64) * (8 * 64);
+      if (vpw == 0) vpw = 8 * 64;
+      if (off + (size_t)vpw * stages[k].wgs > total_vecs) off = 0;
+      L.st[k] = PStage{weights + off, vpw, stages[k].wgs};
+      off += (size_t)vpw * stages[k].wgs;
+      maxw = stages[k].wgs > maxw ? stages[k].wgs : maxw;
+    }
+    // layer l reads the last stage's output of layer l-1 (a kernel boundary lies between them)
+    L.x_in = xbuf + 2048 * ((l + 1) & 1) + 256 * 4;
+    L.xbuf = xbuf + 2048 * (l & 1);
+    L.flags = flags + 8 * l;
+    L.err = err;
+    L.spin_limit = 100ull * 100000ull;
+    hipLaunchKernelGGL((persist_k<DEPTH>), dim3(maxw), dim3(512), 96 * 1024, sa, L);
+  }
+  hipStreamEndCapture(sa, &g);
+  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { printf("instantiate failed\n"); return -1.f; }
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 2; i++) hipGraphLaunch(ge, sa);
+  hipStreamSynchronize(sa);
+  hipEventRecord(a, sa);
+  const int reps = 5;
+  for (int i = 0; i < reps; i++) hipGraphLaunch(ge, sa);
+  hipEventRecord(b, sa);
+  hipStreamSynchronize(sa);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  unsigned h[4096]; hipMemcpy(h, xbuf, sizeof(h), hipMemcpyDeviceToHost);
+  double cs = 0; for (int i = 0; i < 4096; i++) cs += h[i] * (i + 1.0);
+  *checksum = cs;
+  hipGraphExecDestroy(ge); hipGraphDestroy(g);
+  return ms * 1000.f / (reps * layers);
+}
+
 int main() {
   hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
   const size_t bytes = (size_t)3600 << 20;
@@ -140,7 +247,7 @@ int main() {
     for (int r = 0; r < 64; r++) CK(hipMemcpy((char*)w + (size_t)r * h.size() * 4, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   }
   unsigned *xbuf, *flags, *err;
-  CK(hipMalloc(&xbuf, 4096)); CK(hipMemset(xbuf, 0, 4096));
+  CK(hipMalloc(&xbuf, 16384)); CK(hipMemset(xbuf, 0, 16384));
   CK(hipMalloc(&flags, 8192)); CK(hipMemset(flags, 0, 8192)); err = flags + 1500;
   CK(hipDeviceSynchronize());
   const size_t total_vecs = bytes / 16;
@@ -148,7 +255,7 @@ int main() {
   std::vector<Stage> layer = {{13.0, 192}, {0.9, 8}, {8.65, 256}, {60.6, 256}, {30.3, 256}};
   const char* names[3] = {"one stream, stream order", "one stream, counters", "two streams, counters"};
 #define RUN(D)                                                                                                           \
-  for (int mode = 0; mode < 3; mode++) {                                                                                 \
+  for (int mode = 0; mode < 2; mode++) {                                                                                 \
     double cs;                                                                                                           \
     float t = run<D>(sa, sb, w, total_vecs, xbuf, flags, err, layer, layers, mode, &cs);                                 \
     unsigned ran_out = 0; CK(hipMemcpy(&ran_out, err, 4, hipMemcpyDeviceToHost));                                                        \
@@ -157,7 +264,18 @@ int main() {
     if (ran_out) { fflush(stdout); _exit(2); }                                                                                                   \
   }
   RUN(4);
-  RUN(8);
   RUN(14);
+#define RUNP(D)                                                                                              \
+  {                                                                                                          \
+    double cs;                                                                                               \
+    float t = run_persist<D>(sa, w, total_vecs, xbuf, flags, err, layer, layers, &cs);                        \
+    unsigned ran_out = 0; CK(hipMemcpy(&ran_out, err, 4, hipMemcpyDeviceToHost));                            \
+    printf("depth %2d  one persistent kernel per layer  layer %6.2f us  checksum %.0f  wait-ran-out %u\n", D, t, cs, ran_out); \
+    fflush(stdout);                                                                                          \
+    if (ran_out) { _exit(2); }                                                                               \
+  }
+  RUNP(4);
+  RUNP(8);
+  RUNP(14);
   return 0;
 }
