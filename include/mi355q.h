@@ -345,6 +345,78 @@ int mi355q_wi8a16_dequantize(const void* w, const float* scales, void* out, int 
                              int act_dtype, mi355q_stream_t stream);
 
 /* ------------------------------------------------------------------ */
+/* fp8 activations x fp8 weights (W8A8): quantisers and scaled product  */
+/* ------------------------------------------------------------------ */
+/*
+ * All fp8 here is OCP float8_e4m3fn (gfx950), saturated to +-448 before round-to-nearest-even
+ * (csrc/quantization/w8a8/fp8/common.cuh:57-77).  `dtype` is the input element type
+ * (MI355Q_BF16 / _FP16; the three stand-alone quantisers also take MI355Q_FP32); strides count
+ * elements; every scale is fp32 in device memory.
+ *
+ * out[t,n] = fp8(x[t,n] * (1 / scale[(t / group_m) * scale_stride_m + (n / group_n) * scale_stride_n])).
+ * group_m / group_n <= 0 mean the whole extent; per tensor: strides 0, 0; per token: (1, -1) with
+ * strides (1, 0); per channel: (-1, 1) with strides (0, 1); 2-D groups: the scale tensor's strides.
+ * Replaces torch.ops._C.static_scaled_fp8_quant (vllm/_custom_ops.py:1832-1898;
+ * csrc/libtorch_stable/quantization/w8a8/fp8/common.cu:11-76,183-335).
+ */
+int mi355q_static_scaled_fp8_quant(void* out, int64_t out_stride, const void* input, int64_t input_stride,
+                                   const float* scale, int num_tokens, int hidden, int group_m, int group_n,
+                                   int64_t scale_stride_m, int64_t scale_stride_n, int dtype,
+                                   mi355q_stream_t stream);
+/* scale[0] = max|x| / 448 over the whole tensor (written here: a memset node + a reduction kernel),
+ * out = fp8(x * (1 / scale[0])).  Replaces torch.ops._C.dynamic_scaled_fp8_quant (common.cu:78-135,337-381). */
+int mi355q_dynamic_scaled_fp8_quant(void* out, int64_t out_stride, const void* input, int64_t input_stride,
+                                    float* scale, int num_tokens, int hidden, int dtype,
+                                    mi355q_stream_t stream);
+/* scales[t] = max(min(max|x[t,:]|, *scale_ub) / 448, 1 / (448 * 512)) (scale_ub may be NULL),
+ * out[t,:] = fp8(x[t,:] / scales[t]).  Replaces torch.ops._C.dynamic_per_token_scaled_fp8_quant
+ * (common.cu:137-179,383-422). */
+int mi355q_dynamic_per_token_scaled_fp8_quant(void* out, int64_t out_stride, const void* input,
+                                              int64_t input_stride, float* scales, const float* scale_ub,
+                                              int num_tokens, int hidden, int dtype, mi355q_stream_t stream);
+/* out[T,H] fp8 = fp8(float(round(x * rsqrt(mean(x^2) + eps) * w)) * (1 / scale[0])): RMSNorm whose result
+ * passes through the activation dtype and is quantised with a given per-tensor scale.  Replaces
+ * torch.ops._C.rms_norm_static_fp8_quant (csrc/libtorch_stable/layernorm_quant_kernels.cu:22-81,206-246). */
+int mi355q_rms_norm_static_fp8_quant(void* out, const void* input, int64_t input_stride, const void* weight,
+                                     const float* scale, float epsilon, int num_tokens, int hidden, int dtype,
+                                     mi355q_stream_t stream);
+/* residual[T,H] <- round(x + residual) first, then as above on the new residual.  Replaces
+ * torch.ops._C.fused_add_rms_norm_static_fp8_quant (layernorm_quant_kernels.cu:87-202,264-309). */
+int mi355q_fused_add_rms_norm_static_fp8_quant(void* out, const void* input, int64_t input_stride,
+                                               void* residual, const void* weight, const float* scale,
+                                               float epsilon, int num_tokens, int hidden, int dtype,
+                                               mi355q_stream_t stream);
+/* RMSNorm (after an optional residual add; residual may be NULL, else it receives round(x + residual))
+ * quantised with one dynamic scale per token: v = float(x) + float(residual) unrounded,
+ * y = round(round(v * rms) * w), scales[t] = max(min(max|y|, *scale_ub) / 448, 1 / (448 * 512)),
+ * out = fp8(y / scales[t]).  Replaces torch.ops._C.rms_norm_dynamic_per_token_quant with an fp8 output
+ * (vllm/_custom_ops.py:361-…; csrc/libtorch_stable/quantization/fused_kernels/
+ * fused_layernorm_dynamic_per_token_quant.cu:11-91,174-206, layernorm_utils.cuh:17-228). */
+int mi355q_rms_norm_dynamic_per_token_quant(void* out, float* scales, const void* input, int64_t input_stride,
+                                            const void* weight, const float* scale_ub, void* residual,
+                                            float epsilon, int num_tokens, int hidden, int dtype,
+                                            mi355q_stream_t stream);
+/* out[T,d] fp8 = fp8(float(round(round(silu(x[:, :d])) * x[:, d:])) * (1 / scale[0])), input [T, 2d]
+ * contiguous.  Replaces torch.ops._C.silu_and_mul_quant
+ * (csrc/libtorch_stable/quantization/activation_kernels.cu:34-109,584-…). */
+int mi355q_silu_and_mul_quant(void* out, const void* input, const float* scale, int num_tokens, int d,
+                              int dtype, mi355q_stream_t stream);
+/*
+ * C[M,N] (out_dtype) = round((A[M,K] . W[N,K]^T) * scale_a[m] * scale_b[n] + bias[n]): fp8 x fp8 products
+ * accumulated in fp32 on the matrix cores.  A: fp8 [M, K], row stride lda; W: fp8 [N, K], row stride
+ * ldw (the checkpoint's layout; the reference passes its transpose view); K, lda, ldw multiples of
+ * 16.  scale_a: 1 element (per tensor) or M (per token); scale_b: 1 or N (per output channel).
+ * bias: out_dtype [N] or NULL.  Up to 64 rows run on the weight-streaming kernel, more on the tiled one.
+ * Replaces rocm_per_tensor_float_w8a8_scaled_mm_impl = ops.wvSplitKQ for <= 4 rows, else
+ * torch._scaled_mm (vllm/model_executor/kernels/linear/scaled_mm/rocm.py:19-52; wvSplitKQ:
+ * vllm/_custom_ops.py:2213-…, csrc/rocm/skinny_gemms.cu:1885-2345) and the per-token / per-channel
+ * torch._scaled_mm routes (scaled_mm/pytorch.py).
+ */
+int mi355q_fp8_scaled_mm(const void* a, int64_t lda, const void* w, int64_t ldw, const float* scale_a,
+                         int scale_a_numel, const float* scale_b, int scale_b_numel, const void* bias, void* c,
+                         int64_t ldc, int M, int N, int K, int out_dtype, mi355q_stream_t stream);
+
+/* ------------------------------------------------------------------ */
 /* Unquantized skinny linear (lm_head, bf16 decode comparator)         */
 /* ------------------------------------------------------------------ */
 /* C[M,N] = A[M,K] * W[N,K]^T (+ bias); M <= 16 per pass.  Replaces

@@ -401,3 +401,96 @@ def gptq8_gemm(a_bits, q, scales_bits, G, bias_bits=None, dt=BF16, round_weight=
     if bias_bits is not None:
         out = f32_to_h16(h16_to_f32(out, dt) + h16_to_f32(bias_bits, dt)[None, :], dt)
     return out
+
+
+# ---- fp8 activation quantisers and the fp8 x fp8 scaled product ---------------
+FP32 = 2
+_i64 = ctypes.c_int64
+
+
+def _in(x, dt):
+    """2-D input: fp32 array for dt = FP32, uint16 bit patterns otherwise (C-contiguous)."""
+    return np.ascontiguousarray(x, dtype=np.float32 if dt == FP32 else np.uint16)
+
+
+def static_scaled_fp8_quant(x, scale, group_shape=None, dt=BF16):
+    """scale: 0-D / [1] (per tensor), 1-D with group_shape (-1, 1) or (1, -1), or 2-D [T/gm, H/gn]."""
+    x = _in(x, dt)
+    T, H = x.shape
+    scale = np.ascontiguousarray(scale, dtype=np.float32)
+    if scale.size == 1:
+        gm, gn, si, sj = T, H, 0, 0
+    elif scale.ndim == 1:
+        gm = T if group_shape[0] == -1 else group_shape[0]
+        gn = H if group_shape[1] == -1 else group_shape[1]
+        si, sj = (0, 1) if T // gm == 1 else (1, 0)
+    else:
+        gm, gn = T // scale.shape[0], H // scale.shape[1]
+        si, sj = scale.shape[1], 1
+    out = np.empty((T, H), dtype=np.uint8)
+    lib().orc_static_scaled_fp8_quant(_p(x), _i64(H), _p(scale), _p(out), _i(T), _i(H), _i(gm), _i(gn), _i64(si),
+                                      _i64(sj), _i(dt))
+    return out
+
+
+def dynamic_scaled_fp8_quant(x, dt=BF16):
+    x = _in(x, dt)
+    T, H = x.shape
+    out, scale = np.empty((T, H), dtype=np.uint8), np.zeros(1, dtype=np.float32)
+    lib().orc_dynamic_scaled_fp8_quant(_p(x), _i64(H), _p(scale), _p(out), _i(T), _i(H), _i(dt))
+    return out, scale
+
+
+def dynamic_per_token_scaled_fp8_quant(x, scale_ub=None, dt=BF16):
+    x = _in(x, dt)
+    T, H = x.shape
+    out, scales = np.empty((T, H), dtype=np.uint8), np.zeros((T, 1), dtype=np.float32)
+    ub = None if scale_ub is None else np.asarray([scale_ub], dtype=np.float32)
+    lib().orc_dynamic_per_token_scaled_fp8_quant(_p(x), _i64(H), _p(scales), _p(ub), _p(out), _i(T), _i(H), _i(dt))
+    return out, scales
+
+
+def rms_norm_static_fp8_quant(x, w, scale, eps, residual=None, dt=BF16):
+    """Returns (fp8 bytes, new residual or None)."""
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    T, H = x.shape
+    res = None if residual is None else np.array(residual, dtype=np.uint16, order="C")
+    out = np.empty((T, H), dtype=np.uint8)
+    sc = np.asarray([scale], dtype=np.float32).reshape(1)
+    lib().orc_rms_norm_static_fp8_quant(_p(x), _i64(H), _p(res), _p(np.ascontiguousarray(w, dtype=np.uint16)), _p(sc),
+                                        _p(out), _i(T), _i(H), _f(eps), _i(dt))
+    return out, res
+
+
+def rms_norm_dynamic_per_token_quant(x, w, eps, scale_ub=None, residual=None, dt=BF16):
+    """Returns (fp8 bytes, scales [T, 1], new residual or None)."""
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    T, H = x.shape
+    res = None if residual is None else np.array(residual, dtype=np.uint16, order="C")
+    out, scales = np.empty((T, H), dtype=np.uint8), np.zeros((T, 1), dtype=np.float32)
+    ub = None if scale_ub is None else np.asarray([scale_ub], dtype=np.float32)
+    lib().orc_rms_norm_dynamic_per_token_quant(_p(x), _i64(H), _p(res), _p(np.ascontiguousarray(w, dtype=np.uint16)),
+                                               _p(ub), _p(scales), _p(out), _i(T), _i(H), _f(eps), _i(dt))
+    return out, scales, res
+
+
+def silu_and_mul_quant(x, scale, dt=BF16):
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    T, d2 = x.shape
+    out = np.empty((T, d2 // 2), dtype=np.uint8)
+    sc = np.asarray([scale], dtype=np.float32).reshape(1)
+    lib().orc_silu_and_mul_quant(_p(x), _p(sc), _p(out), _i(T), _i(d2 // 2), _i(dt))
+    return out
+
+
+def fp8_scaled_mm(a, w, scale_a, scale_b, bias=None, dt=BF16):
+    """a: fp8 bytes [M, K]; w: fp8 bytes [N, K]; scales fp32 with 1 or M / N elements; bias: 16-bit patterns."""
+    a, w = np.ascontiguousarray(a, dtype=np.uint8), np.ascontiguousarray(w, dtype=np.uint8)
+    (M, K), N = a.shape, w.shape[0]
+    sa = np.ascontiguousarray(scale_a, dtype=np.float32).reshape(-1)
+    sb = np.ascontiguousarray(scale_b, dtype=np.float32).reshape(-1)
+    c = np.empty((M, N), dtype=np.uint16)
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.uint16)
+    lib().orc_fp8_scaled_mm(_p(a), _p(w), _p(sa), _i(sa.size), _p(sb), _i(sb.size), _p(b), _p(c), _i(M), _i(N), _i(K),
+                            _i(dt))
+    return c

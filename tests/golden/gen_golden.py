@@ -605,8 +605,99 @@ def gen_moe():
     save("moe", names=np.array(names), restated=np.array([restated]), **out)
 
 
+def gen_fp8_w8a8():
+    """fp8 activation quantisers and the scaled product.
+    * dynamic per-token / per-tensor quantisation: the reference's own test oracles
+      tests/kernels/quant_utils.py:22-88 (imported; their `as_float32_tensor` pins device="cuda", so it is
+      pointed at the CPU here) on the inputs of tests/kernels/quantization/test_fp8_quant.py:57-108;
+    * static quantisation with group shapes: quant_utils.scaled_quantize (imported), test_fp8_quant.py:135-221;
+    * RMSNorm + per-token quantisation: the reference test's composite
+      (tests/kernels/core/test_fused_quant_layernorm.py:136-182: native RMSNorm, then per-token quantisation);
+    * scaled product: torch._scaled_mm on CPU with the inputs of
+      tests/kernels/quantization/test_rocm_skinny_gemms.py:250-279."""
+    tq = imp("tests.kernels.quant_utils")
+    tq.as_float32_tensor = lambda x: torch.as_tensor(x, dtype=torch.float32, device="cpu")
+    assert tq.FP8_DTYPE == torch.float8_e4m3fn, tq.FP8_DTYPE
+    out, names = {}, []
+    # dynamic quantisers
+    for T, H, dtype, with_ub in [(1, 17, torch.bfloat16, False), (7, 1024, torch.bfloat16, True), (7, 1025, torch.float32, False),
+                                 (7, 1026, torch.bfloat16, True), (3, 5137, torch.float32, True), (16, 1024, torch.bfloat16, False)]:
+        torch.manual_seed(0)
+        tag = f"dyn_{T}x{H}_{'bf16' if dtype == torch.bfloat16 else 'f32'}_{int(with_ub)}"
+        x = torch.rand(T, H, dtype=dtype) + 1e-6
+        ub = torch.mean(x).to(torch.float32) if with_ub else None
+        q_tok, s_tok = tq.ref_dynamic_per_token_quant(x, tq.FP8_DTYPE, ub)
+        q_ten, s_ten = tq.ref_dynamic_per_tensor_fp8_quant(x)
+        names.append(tag)
+        out[tag + "_x"] = bits16(x) if dtype == torch.bfloat16 else x.numpy()
+        if with_ub:
+            out[tag + "_ub"] = ub.reshape(1).numpy()
+        out[tag + "_q_tok"], out[tag + "_s_tok"] = bits8(q_tok), s_tok.numpy()
+        out[tag + "_q_ten"], out[tag + "_s_ten"] = bits8(q_ten), s_ten.numpy()
+    # static quantisation with group shapes
+    gnames = []
+    for T, H, gs in [(128, 256, (-1, -1)), (128, 256, (-1, 1)), (128, 256, (1, -1)), (128, 256, (-1, 128)), (128, 256, (1, 128)),
+                     (128, 256, (128, 128)), (128, 256, (1, 64)), (128, 256, (1, 16)), (128, 256, (4, 256))]:
+        for dtype in (torch.bfloat16, torch.float32) if gs in ((-1, -1), (1, 16), (1, -1)) else (torch.bfloat16,):
+            torch.manual_seed(0)
+            tag = f"static_{T}x{H}_{gs[0]}_{gs[1]}_{'bf16' if dtype == torch.bfloat16 else 'f32'}"
+            x = torch.rand(T, H, dtype=dtype)
+            q, sc = qu.scaled_quantize(x, gs, tq.FP8_DTYPE, compute_dtype=torch.float32)
+            gnames.append(tag)
+            out[tag + "_x"] = bits16(x) if dtype == torch.bfloat16 else x.numpy()
+            out[tag + "_gs"] = np.array(gs)
+            out[tag + "_scale"] = sc.numpy()
+            out[tag + "_q"] = bits8(q)
+    # RMSNorm (+ residual) -> per-token fp8 (the reference test's composite)
+    nnames = []
+    for T, H, add_res, with_ub in [(1, 64, False, False), (1, 1024, True, False), (5, 1027, True, True), (4, 5120, False, True),
+                                   (3, 5137, True, False)]:
+        torch.manual_seed(0)
+        tag = f"normq_{T}x{H}_{int(add_res)}_{int(with_ub)}"
+        w = torch.empty(H, dtype=torch.bfloat16).normal_(mean=1.0, std=0.1)
+        x = torch.randn(T, H, dtype=torch.bfloat16) * (1 / H)
+        res = torch.randn(T, H, dtype=torch.bfloat16) * (1 / H) if add_res else None
+        if add_res:
+            normed, new_res = _native(ln.fused_add_rms_norm)(x.clone(), res.clone(), w, 1e-6)
+        else:
+            normed, new_res = _native(ln.rms_norm)(x, w, 1e-6), None
+        ub = torch.mean(normed).to(torch.float32) if with_ub else None
+        q, sc = tq.ref_dynamic_per_token_quant(normed, tq.FP8_DTYPE, ub)
+        nnames.append(tag)
+        out[tag + "_x"], out[tag + "_w"] = bits16(x), bits16(w)
+        if add_res:
+            out[tag + "_res"], out[tag + "_new_res"] = bits16(res), bits16(new_res)
+        if with_ub:
+            out[tag + "_ub"] = ub.reshape(1).numpy()
+        out[tag + "_normed"] = bits16(normed)
+        out[tag + "_q"], out[tag + "_s"] = bits8(q), sc.numpy()
+    # scaled product
+    mnames = []
+    for n, k, m, dtype, biased in [(1, 64, 64, torch.bfloat16, False), (4, 80, 80, torch.float16, True), (3, 512, 528, torch.bfloat16, True),
+                                   (4, 1024, 256, torch.bfloat16, False), (33, 512, 256, torch.bfloat16, True),
+                                   (200, 256, 384, torch.float16, False)]:
+        torch.manual_seed(0)
+        tag = f"mm_{n}x{k}x{m}_{'bf16' if dtype == torch.bfloat16 else 'f16'}_{int(biased)}"
+        xav = (2 / k) ** 0.5
+        A = (torch.rand(n, k) * 2 - 1) * xav
+        B = (torch.rand(m, k) * 2 - 1) * xav
+        A8, sa = tq.ref_dynamic_per_tensor_fp8_quant(A)
+        B8, sb = tq.ref_dynamic_per_tensor_fp8_quant(B)
+        bias = (torch.rand(m, dtype=dtype) * 2 - 1) if biased else None
+        ref = torch._scaled_mm(A8, B8.t(), out_dtype=dtype, scale_a=sa, scale_b=sb, bias=bias)
+        mnames.append(tag)
+        out[tag + "_a"], out[tag + "_b"] = bits8(A8), bits8(B8)
+        out[tag + "_sa"], out[tag + "_sb"] = sa.numpy(), sb.numpy()
+        if biased:
+            out[tag + "_bias"] = bits16(bias)
+        out[tag + "_ref"] = bits16(ref)
+        out[tag + "_dt"] = np.array([0 if dtype == torch.bfloat16 else 1])
+    save("fp8_w8a8", dyn_names=np.array(names), static_names=np.array(gnames), normq_names=np.array(nnames),
+         mm_names=np.array(mnames), **out)
+
+
 GENERATORS = {"pack": gen_pack, "quantize": gen_quantize, "w4a16": gen_w4a16, "awq": gen_awq, "rmsnorm": gen_rmsnorm,
-              "rope": gen_rope, "paged_attn": gen_paged_attn, "sampler": gen_sampler, "sampler_topk_topp": gen_sampler_topk_topp, "w8a16": gen_w8a16, "moe": gen_moe}
+              "rope": gen_rope, "paged_attn": gen_paged_attn, "sampler": gen_sampler, "sampler_topk_topp": gen_sampler_topk_topp, "w8a16": gen_w8a16, "moe": gen_moe, "fp8_w8a8": gen_fp8_w8a8}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or GENERATORS):

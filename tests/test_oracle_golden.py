@@ -267,3 +267,73 @@ def test_gptq_bit_strings_of_2_and_3_bit_checkpoints():
     assert (qb & 1) == (vals[10] >> 2) and all(((qb >> (1 + 3 * i)) & 7) == vals[11 + i] for i in range(10))
     assert (qb >> 31) == (vals[21] & 1) and (qc & 3) == (vals[21] >> 1)
     assert all(((qc >> (2 + 3 * i)) & 7) == vals[22 + i] for i in range(10))
+
+
+# ---- fp8 activation quantisers and the scaled product (fixture fp8_w8a8) ----------------------
+def _fp8_ulps(a, b):
+    """Distance in representable e4m3 steps (sign-magnitude bytes mapped onto one ordered line)."""
+    def line(x):
+        x = x.astype(np.int32)
+        return np.where(x & 0x80, -(x & 0x7f), x & 0x7f)
+    return np.abs(line(a) - line(b))
+
+
+def _fp8_in(g, tag):
+    x = g[tag + "_x"]
+    return x, (orc.FP32 if x.dtype == np.float32 else orc.BF16)
+
+
+def test_fp8_dynamic_quantisers_match_the_reference_test_oracles(golden):
+    """ref_dynamic_per_token_quant / ref_dynamic_per_tensor_fp8_quant (tests/kernels/quant_utils.py:22-88)
+    are what the reference's test_fp8_quant.py holds the kernels to, bit for bit."""
+    g = golden("fp8_w8a8")
+    for tag in g["dyn_names"]:
+        x, dt = _fp8_in(g, tag)
+        ub = float(g[tag + "_ub"][0]) if tag + "_ub" in g else None
+        q, s = orc.dynamic_per_token_scaled_fp8_quant(x, ub, dt)
+        assert np.array_equal(s, g[tag + "_s_tok"]), tag
+        assert np.array_equal(q, g[tag + "_q_tok"]), tag
+        q, s = orc.dynamic_scaled_fp8_quant(x, dt)
+        assert np.array_equal(s, g[tag + "_s_ten"]), tag
+        assert np.array_equal(q, g[tag + "_q_ten"]), tag
+
+
+def test_fp8_static_quantiser_matches_scaled_quantize(golden):
+    """quant_utils.scaled_quantize divides by the scale where the kernel multiplies by its reciprocal; the
+    reference test (test_fp8_quant.py:186,219) therefore allows rtol 0.12 = one e4m3 step."""
+    g = golden("fp8_w8a8")
+    for tag in g["static_names"]:
+        x, dt = _fp8_in(g, tag)
+        gs, scale = tuple(int(v) for v in g[tag + "_gs"]), g[tag + "_scale"]
+        q = orc.static_scaled_fp8_quant(x, scale, gs, dt)
+        d = _fp8_ulps(q, g[tag + "_q"])
+        assert d.max() <= 1 and (d > 0).mean() < 0.02, (tag, d.max(), (d > 0).mean())
+        # a 1-D scale with an explicit group shape reads the same values
+        if scale.shape[0] == 1 or scale.shape[1] == 1:
+            assert np.array_equal(orc.static_scaled_fp8_quant(x, scale.reshape(-1), gs, dt), q), tag
+
+
+def test_fp8_norm_quant_matches_the_reference_composite(golden):
+    """Fused RMSNorm + per-token quantisation against native RMSNorm followed by the per-token test oracle
+    (test_fused_quant_layernorm.py:136-182); that test accepts scales at rtol 1e-5 and, on gfx950, fp8
+    bytes within one step."""
+    g = golden("fp8_w8a8")
+    for tag in g["normq_names"]:
+        ub = float(g[tag + "_ub"][0]) if tag + "_ub" in g else None
+        res = g[tag + "_res"] if tag + "_res" in g else None
+        q, s, new_res = orc.rms_norm_dynamic_per_token_quant(g[tag + "_x"], g[tag + "_w"], 1e-6, ub, res)
+        np.testing.assert_allclose(s, g[tag + "_s"], rtol=1e-5, atol=1e-8, err_msg=tag)
+        d = _fp8_ulps(q, g[tag + "_q"])
+        assert d.max() <= 1 and (d > 0).mean() < 0.05, (tag, d.max(), (d > 0).mean())
+        if res is not None:
+            assert np.array_equal(new_res, g[tag + "_new_res"]), tag
+
+
+def test_fp8_scaled_mm_matches_torch_scaled_mm(golden):
+    """torch._scaled_mm on CPU at the tolerance of test_rocm_skinny_gemms.py:273-279 (inputs normalised)."""
+    g = golden("fp8_w8a8")
+    for tag in g["mm_names"]:
+        dt = int(g[tag + "_dt"][0])
+        bias = g[tag + "_bias"] if tag + "_bias" in g else None
+        c = orc.fp8_scaled_mm(g[tag + "_a"], g[tag + "_b"], g[tag + "_sa"], g[tag + "_sb"], bias, dt)
+        np.testing.assert_allclose(f32(c, dt), f32(g[tag + "_ref"], dt), atol=1e-3, rtol=1e-2, err_msg=tag)

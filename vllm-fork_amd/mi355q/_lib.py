@@ -63,6 +63,19 @@ _SIGS = {
     "mi355q_w8a16_dequantize": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_wi8a16_gemm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_wi8a16_dequantize": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_static_scaled_fp8_quant": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64,
+                                               c_int, c_vp]),
+    "mi355q_dynamic_scaled_fp8_quant": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_vp]),
+    "mi355q_dynamic_per_token_scaled_fp8_quant": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int,
+                                                          c_vp]),
+    "mi355q_rms_norm_static_fp8_quant": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_int, c_int, c_int, c_vp]),
+    "mi355q_fused_add_rms_norm_static_fp8_quant": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_int, c_int,
+                                                           c_int, c_vp]),
+    "mi355q_rms_norm_dynamic_per_token_quant": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_int, c_int,
+                                                        c_int, c_vp]),
+    "mi355q_silu_and_mul_quant": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "mi355q_fp8_scaled_mm": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_int,
+                                     c_int, c_int, c_int, c_vp]),
     "mi355q_linear_skinny": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_rms_norm": (c_int, [c_vp, c_vp, c_i64, c_vp, c_f32, c_int, c_int, c_int, c_vp]),
     "mi355q_fused_add_rms_norm": (c_int, [c_vp, c_i64, c_vp, c_vp, c_f32, c_int, c_int, c_int, c_vp]),

@@ -562,6 +562,177 @@ def w8a16_gemm(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, bloc
 
 
 # ---------------------------------------------------------------------------
+# fp8 activations x fp8 weights (W8A8)
+# ---------------------------------------------------------------------------
+FP8_DTYPE = torch.float8_e4m3fn   # gfx950 is OCP fp8 (vllm/platforms/rocm.py: fp8_dtype())
+
+
+def _rows2d(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.ndim != 2 or t.stride(-1) != 1:
+        raise RuntimeError(f"{what} must be 2-D with a contiguous last dimension")
+    return t
+
+
+def scaled_fp8_quant(input: torch.Tensor, scale: torch.Tensor | None = None, num_token_padding: int | None = None,
+                     scale_ub: torch.Tensor | None = None, use_per_token_if_dynamic: bool = False,
+                     output: torch.Tensor | None = None,
+                     group_shape: tuple[int, int] | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """ops.scaled_fp8_quant (vllm/_custom_ops.py:1832-1898): static quantisation with the given scale
+    (per tensor, 1-D per token / per channel with `group_shape`, or 2-D groups), else dynamic per tensor
+    or per token (optionally capped by `scale_ub`).  Returns (fp8 tensor, scale)."""
+    _need_cuda(input, scale, scale_ub, output)
+    x = _rows2d(input, "scaled_fp8_quant input")
+    T, H = x.shape
+    shape = (max(num_token_padding, T), H) if num_token_padding else (T, H)
+    if output is None:
+        output = torch.empty(shape, device=x.device, dtype=FP8_DTYPE)
+    elif num_token_padding is not None or output.dtype != FP8_DTYPE:
+        raise RuntimeError("scaled_fp8_quant: a given output must be float8_e4m3fn and excludes padding")
+    _rows2d(output, "scaled_fp8_quant output")
+    L, dt, st = _lib.lib(), _dt(x, allow_fp32=True), _stream()
+    if scale is None:
+        if use_per_token_if_dynamic:
+            scale = torch.empty((shape[0], 1), device=x.device, dtype=torch.float32)
+            check(L.mi355q_dynamic_per_token_scaled_fp8_quant(output.data_ptr(), output.stride(0), x.data_ptr(),
+                                                              x.stride(0), scale.data_ptr(), _ptr(scale_ub), T, H, dt, st))
+        else:
+            scale = torch.empty(1, device=x.device, dtype=torch.float32)
+            check(L.mi355q_dynamic_scaled_fp8_quant(output.data_ptr(), output.stride(0), x.data_ptr(), x.stride(0),
+                                                    scale.data_ptr(), T, H, dt, st))
+        return output, scale
+    if scale.dtype != torch.float32:
+        raise RuntimeError("scaled_fp8_quant: scale must be fp32")
+    if scale.ndim == 0 or scale.numel() == 1:
+        gm, gn, si, sj = T, H, 0, 0
+    elif scale.ndim == 1:
+        if group_shape is None or len(group_shape) != 2:
+            raise RuntimeError("1D scale requires explicit group_shape to disambiguate per-channel vs per-token "
+                               "quantization. Use group_shape=(-1, 1) for per-channel or group_shape=(1, -1) for "
+                               "per-token.")
+        gm = T if group_shape[0] == -1 else group_shape[0]
+        gn = H if group_shape[1] == -1 else group_shape[1]
+        if T % gm or H % gn or scale.numel() != (T // gm) * (H // gn):
+            raise RuntimeError(f"1D scale length ({scale.numel()}) does not match group_shape {tuple(group_shape)} "
+                               f"with input shape ({T}, {H})")
+        if T // gm == 1:
+            si, sj = 0, scale.stride(0)
+        elif H // gn == 1:
+            si, sj = scale.stride(0), 0
+        else:
+            raise RuntimeError("1D scale can only be used when one of the scale dimensions is 1. For 2D group "
+                               "scaling, use a 2D scale tensor.")
+    elif scale.ndim == 2:
+        if T % scale.shape[0] or H % scale.shape[1]:
+            raise RuntimeError(f"input shape ({T}, {H}) must be divisible by the scale shape {tuple(scale.shape)}")
+        gm, gn = T // scale.shape[0], H // scale.shape[1]
+        if group_shape is not None:
+            egm = T if group_shape[0] == -1 else group_shape[0]
+            egn = H if group_shape[1] == -1 else group_shape[1]
+            if (egm, egn) != (gm, gn):
+                raise RuntimeError(f"Explicit group_shape {tuple(group_shape)} does not match inferred group shape "
+                                   f"({gm}, {gn}) from 2D scale tensor shape {tuple(scale.shape)}")
+        si, sj = scale.stride(0), scale.stride(1)
+    else:
+        raise RuntimeError(f"scale must be 0D, 1D, or 2D tensor, but got {scale.ndim}D")
+    check(L.mi355q_static_scaled_fp8_quant(output.data_ptr(), output.stride(0), x.data_ptr(), x.stride(0),
+                                           scale.data_ptr(), T, H, gm, gn, si, sj, dt, st))
+    return output, scale
+
+
+def rms_norm_static_fp8_quant(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor,
+                              epsilon: float) -> None:
+    """torch.ops._C.rms_norm_static_fp8_quant (csrc/libtorch_stable/layernorm_quant_kernels.cu:206-246)."""
+    _need_cuda(out, input, weight, scale)
+    H = input.shape[-1]
+    x = input.reshape(-1, H)
+    if not out.is_contiguous() or x.stride(-1) != 1:
+        raise RuntimeError("rms_norm_static_fp8_quant: out must be contiguous, input contiguous in its last dimension")
+    check(_lib.lib().mi355q_rms_norm_static_fp8_quant(out.data_ptr(), x.data_ptr(), x.stride(0), weight.data_ptr(),
+                                                      scale.data_ptr(), float(epsilon), x.shape[0], H, _dt(x), _stream()))
+
+
+def fused_add_rms_norm_static_fp8_quant(out: torch.Tensor, input: torch.Tensor, residual: torch.Tensor,
+                                        weight: torch.Tensor, scale: torch.Tensor, epsilon: float) -> None:
+    """torch.ops._C.fused_add_rms_norm_static_fp8_quant (layernorm_quant_kernels.cu:264-309): residual is
+    updated in place to input + residual."""
+    _need_cuda(out, input, residual, weight, scale)
+    H = input.shape[-1]
+    x = input.reshape(-1, H)
+    if not out.is_contiguous() or not residual.is_contiguous() or x.stride(-1) != 1:
+        raise RuntimeError("fused_add_rms_norm_static_fp8_quant: out and residual must be contiguous")
+    if residual.dtype != input.dtype or weight.dtype != input.dtype:
+        raise RuntimeError("fused_add_rms_norm_static_fp8_quant: residual and weight must have the input's dtype")
+    check(_lib.lib().mi355q_fused_add_rms_norm_static_fp8_quant(out.data_ptr(), x.data_ptr(), x.stride(0),
+                                                                residual.data_ptr(), weight.data_ptr(), scale.data_ptr(),
+                                                                float(epsilon), x.shape[0], H, _dt(x), _stream()))
+
+
+def rms_norm_dynamic_per_token_quant(input: torch.Tensor, weight: torch.Tensor, epsilon: float,
+                                     quant_dtype: torch.dtype = FP8_DTYPE, scale_ub: torch.Tensor | None = None,
+                                     residual: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """ops.rms_norm_dynamic_per_token_quant (vllm/_custom_ops.py:361-…) for fp8 outputs: returns
+    (fp8 tensor, scales [T, 1]); residual, when given, is updated in place."""
+    _need_cuda(input, weight, scale_ub, residual)
+    if quant_dtype != FP8_DTYPE:
+        raise RuntimeError("rms_norm_dynamic_per_token_quant: only float8_e4m3fn outputs are built")
+    H = input.shape[-1]
+    x = input.reshape(-1, H)
+    if x.stride(-1) != 1 or (residual is not None and (not residual.is_contiguous() or residual.dtype != input.dtype)):
+        raise RuntimeError("rms_norm_dynamic_per_token_quant: input must be contiguous in its last dimension and "
+                           "the residual contiguous, of the same dtype")
+    out = torch.empty(input.shape, dtype=FP8_DTYPE, device=input.device)
+    scales = torch.empty((x.shape[0], 1), dtype=torch.float32, device=input.device)
+    check(_lib.lib().mi355q_rms_norm_dynamic_per_token_quant(out.data_ptr(), scales.data_ptr(), x.data_ptr(), x.stride(0),
+                                                             weight.data_ptr(), _ptr(scale_ub), _ptr(residual),
+                                                             float(epsilon), x.shape[0], H, _dt(x), _stream()))
+    return out, scales
+
+
+def silu_and_mul_quant(out: torch.Tensor, input: torch.Tensor, scale: torch.Tensor) -> None:
+    """torch.ops._C.silu_and_mul_quant (csrc/libtorch_stable/quantization/activation_kernels.cu:584-…)."""
+    _need_cuda(out, input, scale)
+    d = input.shape[-1] // 2
+    if not input.is_contiguous() or not out.is_contiguous() or out.shape[-1] != d or out.dtype != FP8_DTYPE:
+        raise RuntimeError("silu_and_mul_quant: input [..., 2d] and out [..., d] (float8_e4m3fn) must be contiguous")
+    check(_lib.lib().mi355q_silu_and_mul_quant(out.data_ptr(), input.data_ptr(), scale.data_ptr(), input.numel() // (2 * d),
+                                               d, _dt(input), _stream()))
+
+
+def fp8_scaled_mm(a: torch.Tensor, weight: torch.Tensor, out_dtype: torch.dtype, scale_a: torch.Tensor,
+                  scale_b: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """(a[M, K] @ weight[N, K]^T) * scale_a * scale_b + bias with fp8 operands and fp32 accumulation:
+    torch._scaled_mm(a, weight.t(), ...) / ops.wvSplitKQ(weight, a, ...) of
+    vllm/model_executor/kernels/linear/scaled_mm/rocm.py:19-52.  scale_a: 1 or M elements, scale_b: 1 or N."""
+    _need_cuda(a, weight, scale_a, scale_b, bias)
+    if a.dtype != FP8_DTYPE or weight.dtype != FP8_DTYPE:
+        raise RuntimeError("fp8_scaled_mm: operands must be float8_e4m3fn")
+    _rows2d(a, "fp8_scaled_mm a")
+    _rows2d(weight, "fp8_scaled_mm weight")
+    (M, K), N = a.shape, weight.shape[0]
+    if weight.shape[1] != K:
+        raise RuntimeError(f"fp8_scaled_mm: a has {K} columns, weight {weight.shape[1]}")
+    if scale_a.dtype != torch.float32 or scale_b.dtype != torch.float32:
+        raise RuntimeError("fp8_scaled_mm: scales must be fp32")
+    if bias is not None and (bias.dtype != out_dtype or bias.numel() != N):
+        raise RuntimeError("fp8_scaled_mm: bias must have the output dtype and N elements")
+    sa, sb = scale_a.reshape(-1), scale_b.reshape(-1)
+    if not sa.is_contiguous() or not sb.is_contiguous():
+        sa, sb = sa.contiguous(), sb.contiguous()
+    out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    check(_lib.lib().mi355q_fp8_scaled_mm(a.data_ptr(), a.stride(0), weight.data_ptr(), weight.stride(0), sa.data_ptr(),
+                                          sa.numel(), sb.data_ptr(), sb.numel(), _ptr(bias), out.data_ptr(), N, M, N, K,
+                                          _DT[out_dtype], _stream()))
+    return out
+
+
+def wvSplitKQ(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype, scale_a: torch.Tensor, scale_b: torch.Tensor,
+              cu_count: int, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """ops.wvSplitKQ (vllm/_custom_ops.py:2213-…): `a` is the weight [N, K], `b` the activations [M, K],
+    scale_a the activations' scale, scale_b the weight's; cu_count is not needed here."""
+    return fp8_scaled_mm(b, a, out_dtype, scale_a, scale_b, bias)
+
+
+# ---------------------------------------------------------------------------
 # 8-bit integer weights (GPTQ 8 bits, symmetric)
 # ---------------------------------------------------------------------------
 def gptq8_repack(qweight: torch.Tensor, scales: torch.Tensor, group_size: int):
