@@ -16,6 +16,13 @@ DEV = "cuda:0"
 TDT = {orc.BF16: torch.bfloat16, orc.FP16: torch.float16, orc.FP32: torch.float32}
 
 
+@pytest.fixture(autouse=True)
+def _kernel_route(monkeypatch):
+    """These tests check this library's kernels at every row count; the library-GEMM route for many rows
+    has its own test."""
+    monkeypatch.setattr(ops, "FP8_MM_BLAS_MIN_TOKENS", 1 << 30)
+
+
 def to_dev(a, dt=orc.BF16):
     if dt == orc.FP32:
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
@@ -287,6 +294,16 @@ def test_fp8_scaled_mm_prompt_rows_vs_oracle(M, N, K, dt):
     if dt == orc.FP16 and M * N > 3_000_000:
         pytest.skip("large shapes in one dtype")
     got, want = _mm_case(M, N, K, dt, True, True, True)
+    np.testing.assert_allclose(got, want, rtol=1e-2, atol=2e-3 * max(1.0, float(np.abs(want).max())))
+
+
+def test_fp8_scaled_mm_many_rows_route(monkeypatch):
+    """Per-tensor scales and 128+ rows go to the library GEMM (the reference's own call above four rows):
+    same oracle, same tolerance, and the same values as the tiled kernel to that tolerance."""
+    monkeypatch.setattr(ops, "FP8_MM_BLAS_MIN_TOKENS", 128)
+    got, want = _mm_case(256, 1024, 512, orc.BF16, False, False, True)
+    np.testing.assert_allclose(got, want, rtol=1e-2, atol=2e-3 * max(1.0, float(np.abs(want).max())))
+    got, want = _mm_case(256, 1024, 512, orc.BF16, True, True, True)      # row scales stay on this library's kernel
     np.testing.assert_allclose(got, want, rtol=1e-2, atol=2e-3 * max(1.0, float(np.abs(want).max())))
 
 

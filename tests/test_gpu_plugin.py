@@ -398,7 +398,7 @@ def test_fp8_weight_only_linear_method(block):
     from mi355q.plugin import Fp8Config
     rng = np.random.default_rng(9)
     hidden, inter, T = 512, 768, 2
-    cfg = Fp8Config(True, "dynamic", weight_block_size=block)
+    cfg = Fp8Config(True, "dynamic", weight_block_size=block, linear_mode="w8a16")
     with torch.device(DEV):
         gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16,
                                         quant_config=cfg, prefix="mlp.gate_up_proj", return_bias=False)
@@ -423,12 +423,53 @@ def test_fp8_weight_only_linear_method(block):
     assert (to_bits(got) == ref).mean() > 0.97
 
 
+@pytest.mark.parametrize("scheme", ["dynamic", "static"])
+def test_fp8_w8a8_linear_method(scheme):
+    """The reference's ROCm route for per-tensor fp8 checkpoints: fused shards requantised to the largest
+    weight scale, activations quantised per tensor (run-time scale or the checkpoint's input_scale), scaled
+    fp8 x fp8 product.  Against the oracle's restatement of each step on the same bytes."""
+    from mi355q.plugin import Fp8Config
+    rng = np.random.default_rng(19)
+    hidden, inter = 512, 384
+    cfg = Fp8Config(True, scheme)
+    with torch.device(DEV):
+        gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=True, params_dtype=torch.bfloat16,
+                                        quant_config=cfg, prefix="mlp.gate_up_proj", return_bias=False)
+    ws = [orc.f32_to_e4m3((rng.standard_normal((inter, hidden)) * 30).astype(np.float32)) for _ in range(2)]
+    wscales, xscales = [0.004, 0.002], [0.02, 0.03]
+    for i in range(2):
+        gu.weight_loader(gu.weight, torch.from_numpy(ws[i]).view(torch.float8_e4m3fn), i)
+        gu.weight_loader(gu.weight_scale, torch.tensor(wscales[i]), i)
+        if scheme == "static":
+            gu.weight_loader(gu.input_scale, torch.tensor(xscales[i]), i)
+    bias = orc.f32_to_h16(rng.standard_normal(2 * inter).astype(np.float32) * 0.1)
+    gu.bias.data.copy_(to_dev(bias))
+    gu.process_weights_after_loading()
+    # shard 1 requantised from scale 0.002 to 0.004 (through fp16, as per_tensor_dequantize does)
+    dq = (torch.from_numpy(ws[1]).view(torch.float8_e4m3fn).to(torch.float16) * np.float32(0.002)).float().numpy()
+    w1 = orc.static_scaled_fp8_quant(dq, np.array([0.004], np.float32), None, orc.FP32)
+    w_all = np.concatenate([ws[0], w1])
+    assert np.array_equal(gu.weight.data.view(torch.uint8).cpu().numpy(), w_all)
+    assert gu.weight_scale.tolist() == [np.float32(0.004)]
+    for T in (1, 3, 40, 150):
+        x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+        if scheme == "static":
+            xs = np.array([0.03], np.float32)
+            xq = orc.static_scaled_fp8_quant(x, xs)
+        else:
+            xq, xs = orc.dynamic_scaled_fp8_quant(x)
+        ref = orc.fp8_scaled_mm(xq, w_all, xs, np.array([0.004], np.float32), bias)
+        got = gu(to_dev(x))
+        np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=1e-2)
+        assert (to_bits(got) == ref).mean() > 0.97
+
+
 def test_fp8_online_quantisation_of_16bit_checkpoint():
     from mi355q.plugin import Fp8Config
     rng = np.random.default_rng(10)
     K, N, T = 256, 128, 3
     with torch.device(DEV):
-        lin = RowParallelLinear(K, N, bias=False, params_dtype=torch.bfloat16, quant_config=Fp8Config(False, "dynamic"),
+        lin = RowParallelLinear(K, N, bias=False, params_dtype=torch.bfloat16, quant_config=Fp8Config(False, "dynamic", linear_mode="w8a16"),
                                 prefix="o_proj", return_bias=False)
     w = torch.from_numpy((rng.standard_normal((N, K)) * 0.05).astype(np.float32)).to(torch.bfloat16)
     lin.weight_loader(lin.weight, w)

@@ -361,6 +361,7 @@ def test_fp8_config_parsing():
 def test_fp8_per_tensor_scales_expand_per_channel_and_shard(tp):
     from mi355q.plugin import Fp8Config
     c = Fp8Config.from_config({"quant_method": "fp8", "activation_scheme": "static"})
+    c.linear_mode = "w8a16"
     rng = np.random.default_rng(3)
     hidden, head, H, KVH = 128, 64, 4, 2
     full = {n: torch.from_numpy(rng.integers(0, 120, size=(w, hidden), dtype=np.uint8)).view(torch.float8_e4m3fn)
@@ -381,6 +382,41 @@ def test_fp8_per_tensor_scales_expand_per_channel_and_shard(tp):
         assert torch.equal(qkv.weight.data.view(torch.uint8), exp)
         assert qkv.weight_scale.tolist() == [0.5] * hq + [0.25] * hkv + [2.0] * hkv
         assert qkv.input_scale is None and qkv.mi355q_scale_block is None
+
+
+def test_fp8_w8a8_requantises_fused_shards_to_the_largest_scale(tp):
+    """process_fp8_weight_tensor_strategy (fp8_utils.py:1321-1346 -> w8a8_utils.py:76-107): one weight scale for
+    the fused layer, shards with a smaller scale dequantised through fp16 and requantised; the static input
+    scale becomes the largest of the shards' (fp8.py:397-399); a fused checkpoint that loads a single scale
+    is left alone."""
+    from mi355q.plugin import Fp8Config
+    tp(0, 1)
+    c = Fp8Config.from_config({"quant_method": "fp8", "activation_scheme": "static"})
+    assert c.linear_mode == "w8a8"
+    rng = np.random.default_rng(5)
+    hidden, inter = 64, 48
+    gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16, quant_config=c, prefix="gate_up")
+    w = [torch.from_numpy(rng.integers(0, 120, size=(inter, hidden), dtype=np.uint8)).view(torch.float8_e4m3fn) for _ in range(2)]
+    for i, (ws, xs) in enumerate([(0.5, 0.125), (0.25, 0.75)]):
+        gu.weight_loader(gu.weight, w[i], i)
+        gu.weight_loader(gu.weight_scale, torch.tensor(ws), i)
+        gu.weight_loader(gu.input_scale, torch.tensor(xs), i)
+    gu.process_weights_after_loading()
+    assert gu.weight_scale.tolist() == [0.5] and gu.input_scale.tolist() == [0.75]
+    assert torch.equal(gu.weight.data[:inter].view(torch.uint8), w[0].view(torch.uint8))      # 0.5 / 0.5: unchanged
+    want = ((w[1].to(torch.float16) * 0.25).float() * (1 / 0.5)).to(torch.float8_e4m3fn)
+    assert torch.equal(gu.weight.data[inter:].view(torch.uint8), want.view(torch.uint8))
+    # one scale in the checkpoint for the whole fused weight: the other slot keeps its sentinel
+    gu2 = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16,
+                                     quant_config=Fp8Config(True, "dynamic"), prefix="gate_up")
+    both = torch.cat(w)
+    gu2.weight.data.copy_(both)
+    gu2.weight_scale.data[0] = 0.125
+    gu2.process_weights_after_loading()
+    assert gu2.weight_scale.tolist() == [0.125] and torch.equal(gu2.weight.data.view(torch.uint8), both.view(torch.uint8))
+    assert gu2.input_scale is None
+    with pytest.raises(ValueError, match="Unsupported fp8 linear mode"):
+        Fp8Config(True, "dynamic", linear_mode="w4a8")
 
 
 def test_fp8_block_scales_shard_on_tiles(tp):

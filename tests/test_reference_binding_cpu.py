@@ -243,3 +243,32 @@ def test_awq_config_override_resolves_and_repacks(vllm_ref, monkeypatch):
     from mi355q import ops
     zc = ops.scales_row_major(w, zc=True).view(torch.int16).numpy().view(np.uint16)
     assert np.array_equal(zc, (0x6400 + z).astype(np.uint16))      # fp16(1024 + z)
+
+
+def test_fp8_scaled_mm_kernel_is_chosen_by_the_forks_selector(vllm_ref, monkeypatch):
+    """init_fp8_linear_kernel (kernels/linear/__init__.py:615-685) on a ROCm platform returns the MI355X class
+    for per-tensor and dynamic per-token activations, leaves per-group (block) activations to the fork's
+    block kernels, and the instance quantises through this package's op."""
+    qu = _imp("vllm.model_executor.layers.quantization.utils.quant_utils")
+    smm = _imp("vllm.model_executor.kernels.linear.scaled_mm.ScaledMMLinearKernel")
+    lst = vllm_ref.linear._POSSIBLE_FP8_KERNELS[vllm_ref.platform.PlatformEnum.ROCM]
+    names = [k.__name__ for k in lst]
+    assert names[0] == "MI355XFP8ScaledMMLinearKernel" and names.count("MI355XFP8ScaledMMLinearKernel") == 1
+    assert "ROCmFP8ScaledMMLinearKernel" in names and issubclass(lst[0], smm.FP8ScaledMMLinearKernel)
+    monkeypatch.setattr(vllm_ref.linear, "current_platform", _RocmPlatform(vllm_ref.platform.PlatformEnum.ROCM))
+    monkeypatch.setattr(vllm_ref.linear, "_get_linear_backend", lambda: "auto", raising=False)
+    for act in (qu.kFp8StaticTensorSym, qu.kFp8DynamicTensorSym, qu.kFp8DynamicTokenSym):
+        k = vllm_ref.linear.init_fp8_linear_kernel(activation_quant_key=act, weight_quant_key=qu.kFp8StaticTensorSym,
+                                                   input_dtype=torch.bfloat16, out_dtype=torch.bfloat16,
+                                                   weight_shape=(6144, 4096))
+        assert type(k).__name__ == "MI355XFP8ScaledMMLinearKernel"
+        assert k.quant_fp8.static == act.scale.static and k.quant_fp8.per_token == act.scale.group_shape.is_per_token()
+    cfg = smm.FP8ScaledMMLinearLayerConfig(weight_quant_key=qu.kFp8StaticTensorSym, activation_quant_key=qu.kFp8DynamicTokenSym,
+                                           weight_shape=(6144, 4100), input_dtype=torch.bfloat16, out_dtype=torch.bfloat16)
+    ok, why = lst[0].can_implement(cfg)
+    assert not ok and "multiple of 16" in why
+    with pytest.raises(RuntimeError, match="device tensors"):   # no CPU compute path behind apply_weights
+        layer = torch.nn.Module()
+        layer.weight = torch.zeros(64, 32).to(torch.float8_e4m3fn).t()
+        layer.weight_scale, layer.input_scale = torch.ones(1), None
+        k.apply_weights(layer, torch.zeros(2, 64, dtype=torch.bfloat16))

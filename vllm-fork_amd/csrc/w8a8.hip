@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512) void fp8_mm_skinny_kernel(
     const uint8_t* __restrict__ a, int64_t lda, const uint8_t* __restrict__ w, int64_t ldw,
     const float* __restrict__ scale_a, int sa_stride, const float* __restrict__ scale_b, int sb_stride,
     const uint16_t* __restrict__ bias, uint16_t* __restrict__ c, int64_t ldc, int M, int N, int K) {
-  constexpr int NW = 8, U = 4;   // waves per workgroup, K units in flight per wave
+  constexpr int NW = 8, U = R * T > 4 ? 2 : 4;   // waves per workgroup, K units in flight per wave
   __shared__ __attribute__((aligned(16))) float red[NW][R * T][16][16];   // [wave][tile][token][channel]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kq = lane >> 4, ml = lane & 15;
@@ -325,12 +325,18 @@ __global__ __launch_bounds__(512) void fp8_mm_skinny_kernel(
 #pragma unroll
     for (int t = 0; t < T; t++) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int units = (K + 63) >> 6;
+  // every workgroup starts its sweep of K at a different unit, so that the chip's requests at any one
+  // time are spread over K (rows lie a row stride apart, often a power of two)
+  const int rot = (int)((blockIdx.x * 37u) % (unsigned)units);
   for (int u0 = wave; u0 < units; u0 += NW * U) {
     u32x4 wv[U][R], av[U][T];
 #pragma unroll
     for (int j = 0; j < U; j++) {
-      const int u = u0 + j * NW;
-      const bool live = 64 * u + 16 * kq < K;
+      int u = u0 + j * NW;
+      const bool in_range = u < units;
+      u += rot;
+      if (u >= units) u -= units;
+      const bool live = in_range && 64 * u + 16 * kq < K;
       const int off = live ? 64 * u + 16 * kq : 0;   // clamped to the row's start: the loads stay unconditional
 #pragma unroll
       for (int r = 0; r < R; r++) wv[j][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[r] + off));

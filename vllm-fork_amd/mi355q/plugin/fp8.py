@@ -1,15 +1,27 @@
-"""fp8 (float8_e4m3fn) checkpoints, run weight-only: fp8 weights x 16-bit activations.
+"""fp8 (float8_e4m3fn) checkpoints.
 
 Mirrors vllm/model_executor/layers/quantization/fp8.py:92-231 (Fp8Config), :234-456
 (Fp8LinearMethod: weight [N, K] fp8; `weight_scale` one fp32 per logical matrix, or
 `weight_scale_inv` [ceil(N/bn), ceil(K/bk)] for block-quantised checkpoints) and :819-…
-(Fp8KVCacheMethod).  On ROCm the reference runs these checkpoints as w8a8 scaled-mm and has no
-weight-only kernel (kernels/linear/__init__.py:405-407); this method keeps activations in
-16 bits: out = x @ (fp8(W) * scale)^T, the arithmetic of the reference's dequantise-then-linear
-fallback (:433-454).  `input_scale` tensors of static-activation checkpoints are accepted and
-ignored.  16-bit checkpoints are quantised per tensor at load time
-(quantization/online/fp8.py `Fp8PerTensorOnlineLinearMethod`).
+(Fp8KVCacheMethod).  Two ways to run a linear layer (`Fp8Config.linear_mode`, default from
+MI355Q_FP8_LINEAR, else "w8a8"):
+
+  w8a8   what the reference does on ROCm for per-tensor checkpoints: the logical matrices of a fused
+         layer are requantised to their largest scale (w8a8_utils.py:76-107), activations are quantised
+         to fp8 -- with the checkpoint's `input_scale` (static scheme, the largest over the fused
+         shards, fp8.py:397-399) or with a per-tensor scale found at run time (dynamic scheme on
+         ROCm, fp8.py:282-287) -- and the product runs as a scaled fp8 x fp8 matrix product
+         (kernels/linear/scaled_mm/rocm.py:19-52, ScaledMMLinearKernel.py:135-170).
+  w8a16  weight-only: out = x @ (fp8(W) * scale)^T with 16-bit activations, the arithmetic of the
+         reference's dequantise-then-linear fallback (:433-454); the reference has no such kernel
+         on ROCm (kernels/linear/__init__.py:405-407).  `input_scale` tensors are accepted and ignored.
+         Block-quantised checkpoints always run this way (their w8a8 form needs per-token-group
+         activation scales, which this build does not have).
+
+16-bit checkpoints are quantised per tensor at load time (quantization/online/fp8.py
+`Fp8PerTensorOnlineLinearMethod`).
 """
+import os
 from typing import Any
 
 import torch
@@ -22,6 +34,7 @@ from .parameter import BlockQuantScaleParameter, ModelWeightParameter, PerTensor
 from .registry import QuantizationConfig, register_quantization_config
 
 ACTIVATION_SCHEMES = ["static", "dynamic"]
+LINEAR_MODES = ["w8a8", "w8a16"]
 FP8_MAX = 448.0
 
 
@@ -33,10 +46,14 @@ class Fp8KVCacheMethod(BaseKVCacheMethod):
 class Fp8Config(QuantizationConfig):
     def __init__(self, is_checkpoint_fp8_serialized: bool = False, activation_scheme: str = "dynamic",
                  ignored_layers: list[str] | None = None, weight_block_size: list[int] | None = None,
-                 store_dtype: str | None = None) -> None:
+                 store_dtype: str | None = None, linear_mode: str | None = None) -> None:
         super().__init__()
         if activation_scheme not in ACTIVATION_SCHEMES:
             raise ValueError(f"Unsupported activation scheme {activation_scheme}")
+        linear_mode = linear_mode or os.environ.get("MI355Q_FP8_LINEAR") or "w8a8"
+        if linear_mode not in LINEAR_MODES:
+            raise ValueError(f"Unsupported fp8 linear mode {linear_mode!r}; expected one of {LINEAR_MODES}")
+        self.linear_mode = linear_mode
         if weight_block_size is not None:
             if not is_checkpoint_fp8_serialized:
                 raise ValueError("The block-wise quantization only supports fp8-serialized checkpoint for now.")
@@ -83,7 +100,7 @@ class Fp8Config(QuantizationConfig):
         if isinstance(layer, LinearBase):
             if is_layer_skipped(prefix, self.ignored_layers, self.packed_modules_mapping):
                 return UnquantizedLinearMethod()
-            return Fp8LinearMethod(self) if self.is_checkpoint_fp8_serialized else Fp8PerTensorOnlineLinearMethod()
+            return Fp8LinearMethod(self) if self.is_checkpoint_fp8_serialized else Fp8PerTensorOnlineLinearMethod(self)
         if isinstance(layer, Attention):
             return Fp8KVCacheMethod(self)
         return None
@@ -113,6 +130,8 @@ class Fp8LinearMethod(LinearMethodBase):
         self.quant_config = quant_config
         self.weight_block_size = quant_config.weight_block_size
         self.block_quant = self.weight_block_size is not None
+        self.w8a8 = quant_config.linear_mode == "w8a8" and not self.block_quant
+        self.act_q_static = quant_config.activation_scheme == "static"
 
     def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
                        params_dtype, **extra_weight_attrs):
@@ -151,7 +170,38 @@ class Fp8LinearMethod(LinearMethodBase):
                 data=torch.full((len(output_partition_sizes),), torch.finfo(torch.float32).min, dtype=torch.float32),
                 weight_loader=loader))
 
+    def _process_w8a8(self, layer) -> None:
+        """process_fp8_weight_tensor_strategy (fp8_utils.py:1321-1346) without the fnuz step: one scale for
+        the whole fused weight; shards whose scale differs are dequantised (through fp16, as
+        per_tensor_dequantize does) and requantised with the largest."""
+        w, ws = layer.weight.data, layer.weight_scale.data.to(torch.float32).reshape(-1)
+        max_s = ws.max()
+        loaded_per_shard = ws[-1] > torch.finfo(torch.float8_e4m3fn).min   # else: a fused checkpoint, one scale loaded
+        if loaded_per_shard and ws.numel() > 1:
+            start = 0
+            for idx, width in enumerate(layer.logical_widths):
+                if width == 0:
+                    continue
+                dq = w[start:start + width].to(torch.float16) * ws[idx]
+                if w.is_cuda:
+                    q, _ = ops.scaled_fp8_quant(dq.contiguous(), scale=max_s.reshape(1))
+                else:   # host-side loading: the same arithmetic in torch
+                    q = (dq.float() * (1.0 / max_s)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+                w[start:start + width] = q
+                start += width
+        _set(layer, "weight", w)
+        _set(layer, "weight_scale", max_s.reshape(1).contiguous())
+        if self.act_q_static:
+            if getattr(layer, "input_scale", None) is None:
+                raise ValueError("static activation scheme needs an input_scale in the checkpoint")
+            _set(layer, "input_scale", layer.input_scale.data.to(torch.float32).max().reshape(1).contiguous())
+        else:
+            _set(layer, "input_scale", None)   # fp8.py:406-409
+        layer.mi355q_scale_block = None
+
     def process_weights_after_loading(self, layer) -> None:
+        if self.w8a8:
+            return self._process_w8a8(layer)
         _set(layer, "weight", layer.weight.data)
         if self.block_quant:
             _set(layer, "weight_scale_inv", layer.weight_scale_inv.data.contiguous())
@@ -169,6 +219,12 @@ class Fp8LinearMethod(LinearMethodBase):
             _set(layer, "input_scale", None)
 
     def apply(self, layer, x, bias=None):
+        if self.w8a8:
+            # FP8ScaledMMLinearKernel.apply_weights (ScaledMMLinearKernel.py:135-170): quantise, multiply
+            x2 = x.reshape(-1, x.shape[-1])
+            xq, xs = ops.scaled_fp8_quant(x2, scale=layer.input_scale.data if self.act_q_static else None)
+            out = ops.fp8_scaled_mm(xq, layer.weight.data, x.dtype, xs, layer.weight_scale.data, bias)
+            return out.reshape(x.shape[:-1] + (out.shape[-1],))
         scales = layer.weight_scale_inv if self.block_quant else layer.weight_scale
         return ops.w8a16_gemm(x, layer.weight.data.view(torch.uint8), scales.data, layer.mi355q_scale_block, bias)
 
@@ -176,8 +232,10 @@ class Fp8LinearMethod(LinearMethodBase):
 class Fp8PerTensorOnlineLinearMethod(Fp8LinearMethod):
     """16-bit checkpoint, quantised at load: scale = max|W| / 448, W8 = fp8(W / scale)."""
 
-    def __init__(self):
-        self.quant_config, self.weight_block_size, self.block_quant = None, None, False
+    def __init__(self, quant_config: Fp8Config | None = None):
+        self.quant_config, self.weight_block_size, self.block_quant = quant_config, None, False
+        self.w8a8 = quant_config is not None and quant_config.linear_mode == "w8a8"
+        self.act_q_static = False   # no calibrated input scale exists for a 16-bit checkpoint
 
     def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
                        params_dtype, **extra_weight_attrs):
@@ -190,5 +248,6 @@ class Fp8PerTensorOnlineLinearMethod(Fp8LinearMethod):
         w = layer.weight.data.to(torch.float32)
         scale = (w.abs().amax() / FP8_MAX).clamp(min=1e-12)
         _set(layer, "weight", (w / scale).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn))
-        _set(layer, "weight_scale", scale.reshape(1).expand(w.shape[0]).contiguous())
+        _set(layer, "weight_scale", scale.reshape(1).contiguous() if self.w8a8
+             else scale.reshape(1).expand(w.shape[0]).contiguous())
         layer.mi355q_scale_block = None

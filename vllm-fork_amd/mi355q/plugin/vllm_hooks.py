@@ -4,6 +4,10 @@ importable).  Uses the fork's public registration points and nothing else:
   * register_linear_kernel(cls, PlatformEnum.ROCM, "mp") appends at the lowest priority
     (kernels/linear/__init__.py:1091-1137), so the classes are then moved to the front of
     _POSSIBLE_KERNELS[PlatformEnum.ROCM] to win choose_mp_linear_kernel (:724-794);
+  * register_linear_kernel(cls, PlatformEnum.ROCM, "fp8") likewise appends to _POSSIBLE_FP8_KERNELS
+    (:352-360), from where init_fp8_linear_kernel (:615-685) picks the first class that can implement
+    the layer: the fp8 x fp8 kernel class is moved to the front as well, so the fork's own
+    Fp8LinearMethod (fp8.py:354-361) runs its per-tensor / per-token checkpoints on it;
   * register_backend(AttentionBackendEnum.CUSTOM, "<path>") (v1/attention/backends/registry.py
     :242-294), selected with --attention-backend CUSTOM; MI355Q_OVERRIDE_ROCM_ATTN=1 also
     replaces the fork's ROCM_ATTN entry, so that the platform's default choice
@@ -78,6 +82,66 @@ def make_mp_kernel_classes():
             _derive(mp_kernel.MI355XW8A16LinearKernel, "MI355XW8A16LinearKernel"))
 
 
+def make_fp8_kernel_class():
+    """FP8ScaledMMLinearKernel subclass of the fork: activation quantisation and the scaled product both
+    run in libmi355q (ScaledMMLinearKernel.py:108-187 drives it: quantise unless the caller hands over an
+    already quantised activation, then apply_scaled_mm)."""
+    import torch
+    from vllm.model_executor.kernels.linear.scaled_mm.ScaledMMLinearKernel import (FP8ScaledMMLinearKernel,
+                                                                                   ScaledMMLinearKernel)
+
+    from .. import ops
+
+    class _Quant:
+        """Stands where the base class keeps its QuantFP8 module: same call, (x, scale, scale_ub) ->
+        (fp8 tensor, scale)."""
+
+        def __init__(self, static: bool, per_token: bool):
+            self.static, self.per_token = static, per_token
+
+        def __call__(self, x, scale=None, scale_ub=None):
+            if self.static:
+                return ops.scaled_fp8_quant(x, scale=scale)
+            return ops.scaled_fp8_quant(x, scale_ub=scale_ub, use_per_token_if_dynamic=self.per_token)
+
+    class MI355XFP8ScaledMMLinearKernel(FP8ScaledMMLinearKernel):
+        @classmethod
+        def is_supported(cls, compute_capability=None):
+            return True, None
+
+        @classmethod
+        def can_implement(cls, c):
+            a, w = c.activation_quant_key.scale, c.weight_quant_key.scale
+            if not (a.group_shape.is_per_tensor() or (a.group_shape.is_per_token() and not a.static)):
+                return False, f"activation scales must be per tensor or dynamic per token, got {a.group_shape}"
+            if not (w.group_shape.is_per_tensor() or w.group_shape.is_per_channel()):
+                return False, f"weight scales must be per tensor or per output channel, got {w.group_shape}"
+            if c.out_dtype not in (None, torch.bfloat16, torch.float16) or c.input_dtype not in (torch.bfloat16, torch.float16):
+                return False, "activations and outputs must be float16 or bfloat16"
+            K = c.weight_shape[1] if len(c.weight_shape) == 2 else 0
+            if K % 16:
+                return False, f"the input size per rank ({K}) must be a multiple of 16"
+            return True, None
+
+        def __init__(self, c, layer_param_names):
+            # what FP8ScaledMMLinearKernel.__init__ (ScaledMMLinearKernel.py:111-121) sets up, with this
+            # package's quantiser where it builds a QuantFP8 module
+            a = c.activation_quant_key.scale
+            self.quant_fp8 = _Quant(a.static, a.group_shape.is_per_token())
+            self.fp8_dtype = ops.FP8_DTYPE
+            ScaledMMLinearKernel.__init__(self, c, layer_param_names)
+
+        def apply_scaled_mm(self, *, A, B, out_dtype, As, Bs, bias, output_shape):
+            # B is the [K, N] transpose view the fork's linear method leaves in layer.weight (fp8.py:400):
+            # its transpose is the checkpoint's [N, K] tensor with contiguous rows
+            w = B.t()
+            if w.stride(-1) != 1:
+                w = w.contiguous()
+            return ops.fp8_scaled_mm(A, w, out_dtype, As, Bs, bias).view(*output_shape)
+
+    return MI355XFP8ScaledMMLinearKernel
+
+
 def make_awq_config_class():
     """AutoAWQConfig subclass of the fork whose plain linear method runs the MI355X kernel."""
     import torch
@@ -116,7 +180,7 @@ def make_awq_config_class():
 
 
 def hook_into_vllm() -> None:
-    from vllm.model_executor.kernels.linear import _POSSIBLE_KERNELS, register_linear_kernel
+    from vllm.model_executor.kernels.linear import _POSSIBLE_FP8_KERNELS, _POSSIBLE_KERNELS, register_linear_kernel
     from vllm.model_executor.layers.quantization import register_quantization_config
     from vllm.platforms.interface import PlatformEnum
     from vllm.v1.attention.backends.registry import AttentionBackendEnum, register_backend
@@ -128,6 +192,12 @@ def hook_into_vllm() -> None:
             continue
         register_linear_kernel(kernel, PlatformEnum.ROCM, "mp")
         lst.insert(pos, lst.pop(lst.index(kernel)))
+
+    fp8_lst = _POSSIBLE_FP8_KERNELS.setdefault(PlatformEnum.ROCM, [])
+    if "MI355XFP8ScaledMMLinearKernel" not in {k.__name__ for k in fp8_lst}:
+        fp8_kernel = make_fp8_kernel_class()
+        register_linear_kernel(fp8_kernel, PlatformEnum.ROCM, "fp8")
+        fp8_lst.insert(0, fp8_lst.pop(fp8_lst.index(fp8_kernel)))
 
     path = "mi355q.plugin.vllm_attention."
     register_backend(AttentionBackendEnum.CUSTOM, path + "MI355XAttentionBackend")
