@@ -153,6 +153,38 @@ def test_gptq_act_order_checkpoint():
     assert (to_bits(lin2(to_dev(x))) == ref2).mean() > 0.98
 
 
+def test_gptq_act_order_checkpoint_with_k_sharded(monkeypatch):
+    """desc_act on a row-parallel layer at TP = 4 (auto_gptq.py:367-378: g_idx sharded, scales held in full):
+    every rank's partial product against the definition W[k, n] = (q[k, n] - 8) * s[g_idx[k], n] on its rows,
+    and the ranks' partial products summed against the unsharded layer's output."""
+    from mi355q.plugin.mp_kernel import MI355XW4A16LinearKernel, MPLinearLayerConfig
+    from mi355q.plugin.scalar_type import scalar_types
+    rng = np.random.default_rng(23)
+    K_full, N, G, TP, T = 2048, 256, 128, 4, 3
+    K = K_full // TP
+    g_full = rng.permutation(np.arange(K_full) // G).astype(np.int32)
+    q = rng.integers(0, 16, size=(K_full, N), dtype=np.int32)
+    s = orc.f32_to_h16((0.01 + 0.02 * rng.random((K_full // G, N))).astype(np.float32))
+    x = orc.f32_to_h16(rng.standard_normal((T, K_full)).astype(np.float32))
+    W = (q - 8).astype(np.float64) * f32(s)[g_full].astype(np.float64)
+    total = np.zeros((T, N))
+    for rank in range(TP):
+        rows = slice(rank * K, (rank + 1) * K)
+        cfg = MPLinearLayerConfig((K_full, N), (K, N), scalar_types.uint4b8, torch.bfloat16, G, False, True)
+        layer = torch.nn.Module()
+        for name, t in (("qweight", torch.from_numpy(orc.gptq_pack(q[rows])).to(DEV)), ("scales", to_dev(s)),
+                        ("qzeros", torch.zeros((K_full // G, N // 8), dtype=torch.int32, device=DEV)),
+                        ("g_idx", torch.from_numpy(g_full[rows]).to(DEV))):
+            layer.register_parameter(name, torch.nn.Parameter(t, requires_grad=False))
+        kernel = MI355XW4A16LinearKernel(cfg, "qweight", "scales", "qzeros", "g_idx")
+        kernel.process_weights_after_loading(layer)
+        got = f32(to_bits(kernel.apply_weights(layer, to_dev(x[:, rows]))))
+        want = f32(x[:, rows]).astype(np.float64) @ W[rows]
+        np.testing.assert_allclose(got, want, rtol=1e-2, atol=2e-2)
+        total += got
+    np.testing.assert_allclose(total, f32(x).astype(np.float64) @ W, rtol=2e-2, atol=5e-2)
+
+
 def test_gptq_8bit_checkpoint():
     """bits=8 GPTQ config -> uint8b128 -> the 8-bit kernel class; bias added to the rounded product."""
     rng = np.random.default_rng(15)

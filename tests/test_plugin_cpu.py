@@ -154,9 +154,11 @@ def test_kernel_selection_and_reasons(monkeypatch):
     assert not ok and "not supported" in reason
     with pytest.raises(ValueError, match="Failed to find a kernel"):
         choose_mp_linear_kernel(_kcfg(weight_type=scalar_types.uint8b128, has_g_idx=True))
-    # activation reordering is served when the whole of K is on the rank, refused when K is sharded
+    # activation reordering is served with the whole of K on the rank and, for symmetric weights, with K sharded
     assert choose_mp_linear_kernel(_kcfg(has_g_idx=True)) is MI355XW4A16LinearKernel
-    for bad, why in ((dict(has_g_idx=True, partition_weight_shape=(2048, 6144)), "g_idx"),
+    assert choose_mp_linear_kernel(_kcfg(has_g_idx=True, partition_weight_shape=(2048, 6144))) is MI355XW4A16LinearKernel
+    for bad, why in ((dict(has_g_idx=True, partition_weight_shape=(2048, 6144), weight_type=scalar_types.uint4,
+                           zero_points=True), "only supported for symmetric"),
                      (dict(act_type=torch.float32), "float16/bfloat16"),
                      (dict(partition_weight_shape=(4096, 100)), "multiple of 64"),
                      (dict(group_size=100), "not divisible"), (dict(weight_type=scalar_types.uint4), "zero points")):
@@ -576,3 +578,50 @@ def test_quantized_lm_head_gets_a_gptq_method_and_vocab_shards(tp):
     w = torch.randn(1000, H).to(torch.bfloat16)
     odd.weight_loader(odd.weight, w)
     assert torch.equal(odd.weight.data[:488], w[512:]) and not odd.weight.data[488:].any()
+
+
+def test_act_order_with_the_input_dimension_sharded_regroups_rows():
+    """A rank of a row-parallel desc_act layer: rows sorted by group, groups padded to sub-groups of 32 with
+    rows of the zero point, scales repeated per sub-group, inputs gathered in the same order; the packed
+    weight unpacks to exactly those rows (host arithmetic of the repack entry point)."""
+    from mi355q import _lib, ops
+    from mi355q.plugin.mp_kernel import MI355XW4A16LinearKernel, MPLinearLayerConfig
+    rng = np.random.default_rng(11)
+    K_full, K, N, G = 1024, 256, 128, 128
+    cfg = MPLinearLayerConfig(full_weight_shape=(K_full, N), partition_weight_shape=(K, N), weight_type=scalar_types.uint4b8,
+                              act_type=torch.bfloat16, group_size=G, zero_points=False, has_g_idx=True)
+    assert MI355XW4A16LinearKernel.can_implement(cfg) == (True, None)
+    g_full = rng.permutation(np.arange(K_full) // G).astype(np.int32)
+    g = g_full[256:512]                                                  # rank 1 of 4
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    scales = torch.from_numpy(rng.random((K_full // G, N), dtype=np.float32)).to(torch.bfloat16)
+    layer = torch.nn.Module()
+    for name, t in (("qweight", torch.from_numpy(orc.gptq_pack(q))), ("scales", scales),
+                    ("qzeros", torch.zeros((K_full // G, N // 8), dtype=torch.int32)), ("g_idx", torch.from_numpy(g))):
+        layer.register_parameter(name, torch.nn.Parameter(t, requires_grad=False))
+    kernel = MI355XW4A16LinearKernel(cfg, "qweight", "scales", "qzeros", "g_idx")
+    kernel.process_weights_after_loading(layer)
+    w, perm = layer.mi355q_weight, layer.mi355q_perm.numpy()
+    counts = np.bincount(g, minlength=K_full // G)
+    K2 = (int(((counts + 31) // 32 * 32).sum()) + 127) // 128 * 128
+    assert (w.K, w.N, w.G) == (K2, N, 32) and perm.shape == (K2,) and layer.g_idx is None and w.zc is None
+    back = np.empty((K2, N), dtype=np.int32)
+    _lib.check(_lib.lib().mi355q_w4a16_unpack_host(w.packed.numpy().ctypes.data, back.ctypes.data, K2, N, w.tile))
+    s_rows = ops.scales_row_major(w).float().numpy()                     # [K2 / 32, N]
+    # the matrix the kernel multiplies, scattered back to the shard's own row order, is the definition
+    W2 = (back - 8).astype(np.float64) * np.repeat(s_rows, 32, axis=0)
+    W = np.zeros((K, N))
+    np.add.at(W, perm, W2)
+    want = (q - 8).astype(np.float64) * scales.float().numpy()[g]
+    assert np.array_equal(W, want)
+    pad_rows = np.ones(K2, dtype=bool)
+    order = np.argsort(g, kind="stable")
+    first, starts = np.cumsum(counts) - counts, np.cumsum((counts + 31) // 32 * 32) - (counts + 31) // 32 * 32
+    pad_rows[starts[g[order]] + (np.arange(K) - first[g[order]])] = False
+    assert np.all(back[pad_rows] == 8)                                   # padding multiplies to zero
+    with pytest.raises(ValueError, match="held in full on every rank"):
+        bad = torch.nn.Module()
+        for name, t in (("qweight", torch.from_numpy(orc.gptq_pack(q))), ("scales", scales[:2]),
+                        ("qzeros", torch.zeros((2, N // 8), dtype=torch.int32)), ("g_idx", torch.from_numpy(g))):
+            bad.register_parameter(name, torch.nn.Parameter(t, requires_grad=False))
+        MI355XW4A16LinearKernel(cfg, "qweight", "scales", "qzeros", "g_idx").process_weights_after_loading(bad)

@@ -111,12 +111,12 @@ class MI355XW4A16LinearKernel(MPLinearKernel):
             return False, f"Quant type {c.weight_type} not supported; supported: {list(cls.SUPPORTED_QUANT_TYPES)}"
         if c.act_type not in (torch.float16, torch.bfloat16):
             return False, "Only float16/bfloat16 activations are supported"
-        if c.has_g_idx and c.partition_weight_shape[0] != c.full_weight_shape[0]:
-            # rows of one scale group are then spread over the ranks: the sorted order that makes
-            # groups contiguous needs the whole of K on one rank.  The fork's own ROCm kernels refuse the
-            # same case (exllama.py:35-41; Triton and Conch refuse g_idx altogether): only its CUDA-only
-            # Marlin route serves it, through the replicated scales of auto_gptq.py:367-378.
-            return False, "Activation reordering (g_idx) with the input dimension sharded is not supported"
+        if c.has_g_idx and c.partition_weight_shape[0] != c.full_weight_shape[0] and c.zero_points:
+            # rows of one scale group are then spread over the ranks; the regrouped layout built for that
+            # case (process_weights_after_loading) pads groups with rows that multiply to zero, which
+            # needs the constant zero point of a symmetric format
+            return False, ("Activation reordering (g_idx) with the input dimension sharded is only supported "
+                           "for symmetric weights")
         if c.weight_type == scalar_types.uint4 and not c.zero_points:
             return False, "uint4 weights need zero points (symmetric checkpoints use uint4b8)"
         K, N = c.partition_weight_shape
@@ -149,6 +149,9 @@ class MI355XW4A16LinearKernel(MPLinearKernel):
         else:
             raise ValueError(f"{self.w_q_name}: shape {tuple(q.shape)} is none of [K/8,N], [N,K/8], [K,N/8] "
                              f"for K={K}, N={N}")
+        if c.has_g_idx and K != c.full_weight_shape[0]:
+            # named through the class: the fork-side kernel class borrows this function without inheriting
+            return MI355XW4A16LinearKernel._process_sharded_act_order(self, layer, q, layout)
         s = w_s.data
         if tuple(s.shape) == (N, K // G) and (K // G != N or getattr(w_s, "output_dim", 1) == 0):
             s = s.t()
@@ -188,6 +191,60 @@ class MI355XW4A16LinearKernel(MPLinearKernel):
         _set_param(layer, "w_zc", w.zc)
         layer.mi355q_weight = ops.PackedW4(getattr(layer, self.w_q_name).data, getattr(layer, self.w_s_name).data,
                                            None if w.zc is None else layer.w_zc.data, K, N, G, w.tile)
+
+    def _process_sharded_act_order(self, layer: torch.nn.Module, q: torch.Tensor, layout: int) -> None:
+        """desc_act checkpoint on a row-parallel layer: this rank holds K of the K_full input features, row k
+        belongs to group g_idx[k] of the K_full / G groups, whose scales every rank holds in full
+        (auto_gptq.py:367-378).  A group has any number of its rows here, so the rows are sorted by group and
+        every group is padded to whole sub-groups of 32 rows with rows of the constant zero point (they
+        multiply to zero whatever input they meet); the kernel then runs with group size 32, each sub-group
+        carrying its group's scales, and the input features are gathered into the same order at run time
+        (padding rows read feature 0)."""
+        c = self.config
+        (K, N), K_full = c.partition_weight_shape, c.full_weight_shape[0]
+        G, SUB = c.group_size, 32
+        if layout != _lib.W_GPTQ:
+            raise ValueError("activation reordering is defined for weights packed along K (GPTQ layout)")
+        _, w_s, _, w_g = self._get_weight_params(layer)
+        scales = w_s.data
+        if tuple(scales.shape) != (K_full // G, N):
+            raise ValueError(f"{self.w_s_name}: shape {tuple(scales.shape)} != ({K_full // G}, {N}) "
+                             "(scales of a reordered checkpoint are held in full on every rank)")
+        if w_g is None or w_g.numel() != K:
+            raise ValueError(f"g_idx must have {K} entries")
+        dev = q.device
+        g = w_g.data.to(device=dev, dtype=torch.int64)
+        if int(g.min()) < 0 or int(g.max()) >= K_full // G:
+            raise ValueError("g_idx names a group outside the checkpoint's scales")
+        order = torch.argsort(g, stable=True)
+        gs = g[order]
+        counts = torch.bincount(gs, minlength=K_full // G)
+        padded = (counts + SUB - 1) // SUB * SUB
+        starts, first = torch.cumsum(padded, 0) - padded, torch.cumsum(counts, 0) - counts
+        K2 = (int(padded.sum()) + 127) // 128 * 128
+        dest = starts[gs] + (torch.arange(K, device=dev) - first[gs])
+        shifts = torch.arange(0, 32, 4, device=dev, dtype=torch.int32)
+        rows = ((q[:, None, :] >> shifts[None, :, None]) & 0xF).reshape(K, N)
+        new_rows = torch.full((K2, N), 8, dtype=torch.int32, device=dev)
+        new_rows[dest] = rows[order]
+        perm = torch.zeros(K2, dtype=torch.int64, device=dev)
+        perm[dest] = order
+        group_of_sub = torch.zeros(K2 // SUB, dtype=torch.int64, device=dev)
+        group_of_sub[: int(padded.sum()) // SUB] = torch.repeat_interleave(torch.arange(K_full // G, device=dev), padded // SUB)
+        new_rows = new_rows.reshape(K2 // 8, 8, N)
+        packed = torch.zeros((K2 // 8, N), dtype=torch.int32, device=dev)
+        for i in range(8):
+            packed |= new_rows[:, i, :] << (4 * i)
+        w = ops.w4a16_repack(packed, scales[group_of_sub].contiguous().to(c.act_type), None, SUB, _lib.W_GPTQ, _lib.ZP_CONST)
+        _set_param(layer, self.w_q_name, w.packed)
+        _set_param(layer, self.w_s_name, w.scales)
+        if self.w_zp_name is not None:
+            _set_param(layer, self.w_zp_name, None)
+        _set_param(layer, self.w_gidx_name, None)
+        _set_param(layer, "w_zc", None)
+        layer.mi355q_perm = perm
+        layer.mi355q_weight = ops.PackedW4(getattr(layer, self.w_q_name).data, getattr(layer, self.w_s_name).data, None,
+                                           K2, N, SUB, w.tile)
 
     # -- run time ----------------------------------------------------------
     def apply_weights(self, layer, x, bias=None):
