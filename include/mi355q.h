@@ -299,6 +299,38 @@ int mi355q_moe_w4a16_gemm(const void* x, int ldx, int x_row_div, const void* pac
                           int slots, int num_experts, int N, int K, int G, int tile, int act_dtype,
                           int fuse_silu_mul, mi355q_stream_t stream);
 /*
+ * Token sort for many-token batches.  expert_ids[slots]: the (local) expert of every (token, choice) slot,
+ * negative for experts held by another rank.  Slots are grouped by expert; every expert's run is padded to
+ * whole tiles of `block` slots:
+ *   sorted_ids[max_tiles * block]  slot index per sorted row, `slots` for padding rows
+ *   tile_expert[max_tiles]         expert of every tile, -1 past the last used tile
+ *   num_tiles[1]                   number of used tiles
+ *   slot_pos[slots]                sorted row of every slot (-1: expert not held here)
+ * max_tiles >= ceil((slots + min(slots, E) * (block - 1)) / block).  The order of an expert's slots inside its
+ * run is not defined (no result depends on it).  Replaces ops.moe_align_block_size
+ * (vllm/_custom_ops.py:2237-2255; csrc/libtorch_stable/moe/moe_align_sum_kernels.cu:326-700; the
+ * reference's expert_ids per block / num_tokens_post_pad are tile_expert / num_tiles * block here).
+ */
+int mi355q_moe_align_block_size(const int32_t* expert_ids, int slots, int num_experts, int block,
+                                int32_t* sorted_ids, int32_t* tile_expert, int32_t* num_tiles, int32_t* slot_pos,
+                                int max_tiles, mi355q_stream_t stream);
+/* Row-tile height of mi355q_moe_w4a16_grouped_mm: the `block` to sort with. */
+int mi355q_moe_grouped_block_rows(void);
+size_t mi355q_moe_w4a16_grouped_mm_workspace_bytes(int rows, int N, int K, int G, int tile);
+/*
+ * Grouped expert GEMM over token-sorted rows: c[r, :] = a[r, :] @ dequant(expert tile_expert[r / block]) for the
+ * rows of the first *num_tiles tiles (other rows are left untouched); a [rows, K] holds the gathered
+ * activations in sorted order (padding rows: any finite values), rows = max_tiles * block.  Same weights,
+ * arithmetic and rounding as mi355q_moe_w4a16_gemm; silu_pairs: SiluAndMul in the epilogue, c is [rows, N/2]
+ * (experts repacked with MI355Q_W_PAIR_HALVES).  Replaces ops.moe_wna16_gemm for prompt batches
+ * (vllm/_custom_ops.py:2307-2342; csrc/libtorch_stable/moe/moe_wna16.cu:16-350) on the sorted layout of
+ * fused_experts_impl (fused_moe.py:1650-1850).
+ */
+int mi355q_moe_w4a16_grouped_mm(const void* a, int lda, const void* packed, const void* scales, const void* zc,
+                                const int32_t* tile_expert, const int32_t* num_tiles, void* c, int rows,
+                                int num_experts, int N, int K, int G, int tile, int act_dtype, int silu_pairs,
+                                void* workspace, size_t workspace_bytes, mi355q_stream_t stream);
+/*
  * out[t, :] = round(sum_j topk_weights[t, j] * expert_out[t * topk + j, :]), fp32 sum in
  * slot order (topk_weights NULL: plain sum).  Replaces ops.moe_sum (vllm/_custom_ops.py:2228;
  * moe_align_sum_kernels.cu) together with the routed-weight multiply of the expert GEMM

@@ -185,7 +185,7 @@ def test_mixtral_sized_expert_layer(monkeypatch):
             acc[t] += tw[t, j] * f32(y[0])
     ref = f32(orc.f32_to_h16(acc))
     for T in (1, 2, 8):
-        for route in ("slots", "all_experts", None):
+        for route in ("slots", "all_experts", "grouped", None):
             monkeypatch.setattr(moe_mod, "FORCE_ROUTE", route)
             out = fused_experts(to_dev(a[:T]), d13, d2, torch.from_numpy(tw[:T]).to(DEV), torch.from_numpy(ids[:T]).to(DEV))
             np.testing.assert_allclose(f32(to_bits(out)), ref[:T], rtol=1e-2, atol=2e-2, err_msg=f"T={T} route={route}")

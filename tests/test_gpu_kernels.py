@@ -1039,11 +1039,86 @@ def test_moe_golden_and_oracle(golden, monkeypatch):
         np.testing.assert_allclose(tw.cpu().numpy(), rw, rtol=1e-5)
         ref = f32(g[tag + "_ref"])
         exact = f32(moe_ref.moe(g[tag + "_a"], w1, w2, rw, rids, G))
-        for route in ("slots", "all_experts", "grouped", None):
+        for route in ("slots", "all_experts", "grouped", "grouped_host", None):
             monkeypatch.setattr(moe_mod, "FORCE_ROUTE", route)
             out = f32(to_bits(fused_experts(a, d13, d2, tw, ids)))
             np.testing.assert_allclose(out, ref, rtol=0, atol=2e-2, err_msg=tag)
             np.testing.assert_allclose(out, exact, rtol=1e-2, atol=2e-3, err_msg=tag)
+
+
+def test_moe_align_block_size():
+    """Token sort of the grouped expert GEMM (ops.moe_align_block_size of the reference,
+    vllm/_custom_ops.py:2237-2255): every expert's run holds exactly its slots, runs are padded to whole
+    tiles with the sentinel, tiles are labelled with their expert, slot_pos inverts the sort; slots of experts
+    held elsewhere (negative ids) are left out."""
+    rng = np.random.default_rng(3)
+    for slots, E in [(1, 4), (130, 8), (4096, 8), (5000, 60), (700, 256)]:
+        ids = rng.integers(-1 if E == 8 else 0, E, size=slots).astype(np.int32)
+        block = _lib.lib().mi355q_moe_grouped_block_rows()
+        sorted_ids, tile_expert, num_tiles, slot_pos = (t.cpu().numpy() for t in ops.moe_align_block_size(
+            torch.from_numpy(ids).to(DEV), E))
+        assert block == 64 and sorted_ids.size == tile_expert.size * block
+        pos, nt = 0, 0
+        for e in range(E):
+            mine = np.nonzero(ids == e)[0]
+            tiles = -(-mine.size // block)
+            run = sorted_ids[pos:pos + tiles * block]
+            assert np.array_equal(np.sort(run[:mine.size]), mine) and np.all(run[mine.size:] == slots), (slots, E, e)
+            assert np.all(tile_expert[nt:nt + tiles] == e)
+            pos, nt = pos + tiles * block, nt + tiles
+        assert int(num_tiles[0]) == nt and np.all(tile_expert[nt:] == -1) and np.all(sorted_ids[pos:] == slots)
+        held = ids >= 0
+        assert np.all(slot_pos[~held] == -1) and np.array_equal(sorted_ids[slot_pos[held]], np.nonzero(held)[0])
+
+
+@pytest.mark.parametrize("awq,pair", [(False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("T", [65, 300])
+def test_moe_grouped_route_for_prompt_batches(T, awq, pair, monkeypatch):
+    """More tokens than the every-expert route takes: token-sorted rows through the grouped expert GEMM (one
+    launch per projection, no host round trip), to the same bar as the other routes -- fp32 scales, one
+    rounding -- with and without zero points, the SiluAndMul epilogue, and an expert map; the route is the
+    default choice at this size and can be captured."""
+    import moe_ref
+    from mi355q.plugin import fused_experts, moe as moe_mod
+    rng = np.random.default_rng(41 + T + awq)
+    E, H, I, G, topk = 6, 1024, 1024, 128, 2
+    def mk(n, k):
+        z = rng.integers(0, 256, size=(E, n // 2, k // G), dtype=np.uint8) if awq else None
+        return (rng.integers(0, 256, size=(E, n, k // 2), dtype=np.uint8),
+                orc.f32_to_h16((0.01 * rng.random((E, n, k // G)) + 0.002).astype(np.float32)), z)
+    w1, w2 = mk(2 * I, H), mk(H, I)
+    emap = np.array([0, 1, -1, 2, 3, 4], dtype=np.int32)
+    local = [0, 1, 3, 4, 5]
+    sub = lambda w, idx: (w[0][idx], w[1][idx], None if w[2] is None else w[2][idx])
+    def dev(w, idx, pair_halves=False):
+        w = sub(w, idx)
+        return ops.moe_w4a16_repack(torch.from_numpy(w[0]).to(DEV), to_dev(w[1]),
+                                    None if w[2] is None else torch.from_numpy(w[2]).to(DEV), G, pair_halves=pair_halves)
+    a = orc.f32_to_h16((0.5 * rng.standard_normal((T, H))).astype(np.float32))
+    ids = np.stack([rng.permutation(E)[:topk] for _ in range(T)]).astype(np.int32)
+    ids[: T // 3] = [4, 1]                                    # a crowded expert: several tiles in one run
+    tw = rng.random((T, topk)).astype(np.float32)
+    for use_map in (False, True):
+        idx = local if use_map else list(range(E))
+        d13, d2 = dev(w1, idx, pair), dev(w2, idx)
+        assert d13.pair_halves == pair and ops.moe_grouped_mm_supported(d13) and ops.moe_grouped_mm_supported(d2)
+        ref = moe_ref.moe(a, sub(w1, idx), sub(w2, idx), tw, ids, G, expert_map=emap if use_map else None)
+        scale_mag = max(1.0, float(np.abs(f32(ref)).max()) / 4)
+        args = (to_dev(a), d13, d2, torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV),
+                torch.from_numpy(emap).to(DEV) if use_map else None)
+        monkeypatch.setattr(moe_mod, "FORCE_ROUTE", None)
+        out = fused_experts(*args)
+        np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=5e-3 * scale_mag)
+        monkeypatch.setattr(moe_mod, "FORCE_ROUTE", "all_experts")
+        other = fused_experts(*args)
+        assert (to_bits(out) == to_bits(other)).mean() > 0.97     # same arithmetic, other summation order at most
+        monkeypatch.setattr(moe_mod, "FORCE_ROUTE", None)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            cap = fused_experts(*args)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cap, out)
 
 
 def test_moe_expert_map_and_sum(monkeypatch):
@@ -1109,13 +1184,14 @@ def test_moe_decode_slots_on_the_burst_kernel(awq, pair, monkeypatch):
     ref = moe_ref.moe(a, sub(w1), sub(w2), tw, ids, G, expert_map=emap)
     ref_rw = moe_ref.moe(a, sub(w1), sub(w2), tw, ids, G, expert_map=emap, round_weight=True)
     scale_mag = max(1.0, float(np.abs(f32(ref)).max()) / 4)   # zero points un-centre the weights: larger outputs
-    for route in ("slots", "all_experts", "grouped"):
+    assert ops.moe_grouped_mm_supported(d13) and ops.moe_grouped_mm_supported(d2)
+    for route in ("slots", "all_experts", "grouped", "grouped_host"):
         monkeypatch.setattr(moe_mod, "FORCE_ROUTE", route)
         out = fused_experts(to_dev(a), d13, d2, torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV),
                             torch.from_numpy(emap).to(DEV))
-        # the grouped route multiplies with weights rounded to 16 bits (the reference's many-token
+        # the host-grouped route multiplies with weights rounded to 16 bits (the reference's many-token
         # arithmetic): compared with the oracle in that mode
-        want = ref_rw if route == "grouped" else ref
+        want = ref_rw if route == "grouped_host" else ref
         np.testing.assert_allclose(f32(to_bits(out)), f32(want), rtol=1e-2, atol=5e-3 * scale_mag, err_msg=route)
     # the slot rows themselves: expert GEMV against the oracle, zero row for the absent expert
     lids = torch.from_numpy(emap[ids.reshape(-1)]).to(DEV)

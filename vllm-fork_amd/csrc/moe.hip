@@ -1,6 +1,8 @@
 // Mixture-of-experts routing and combine for decode.  The expert GEMMs themselves are the
 // W4A16 skinny kernel with per-row expert selection (mi355q_moe_w4a16_gemm in w4a16.hip);
 // here: router softmax + top-k, and the weighted sum of the selected experts' outputs.
+#include <algorithm>
+
 #include "common.h"
 
 namespace mi355q {
@@ -92,9 +94,72 @@ __global__ __launch_bounds__(256) void moe_sum_kernel(uint16_t* __restrict__ out
   *reinterpret_cast<u32x4*>(out + (size_t)t * H + 8 * v) = o;
 }
 
+// Token sort for the grouped expert GEMM (moe_align_block_size of the reference): the (token, expert)
+// slots are grouped by expert, every expert's run is padded to whole row tiles of `block` slots, and
+// each tile is labelled with its expert.  One workgroup; counts, offsets and cursors in LDS.  The
+// order of an expert's slots inside its run depends on arrival order, which no result depends on: a
+// row of the product is a function of its own input row and its expert's weights only.
+__global__ __launch_bounds__(1024) void moe_align_kernel(const int* __restrict__ ids, int slots, int num_experts,
+                                                         int block, int* __restrict__ sorted_ids,
+                                                         int* __restrict__ tile_expert, int* __restrict__ num_tiles,
+                                                         int* __restrict__ slot_pos, int max_tiles) {
+  extern __shared__ int sm[];          // counts[E], offsets[E + 1], cursor[E]
+  int* counts = sm;
+  int* offsets = sm + num_experts;
+  int* cursor = offsets + num_experts + 1;
+  for (int e = threadIdx.x; e < num_experts; e += blockDim.x) { counts[e] = 0; cursor[e] = 0; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < slots; i += blockDim.x) {
+    const int e = ids[i];
+    if (e >= 0 && e < num_experts) atomicAdd(&counts[e], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int off = 0;
+    for (int e = 0; e < num_experts; e++) {
+      offsets[e] = off;
+      const int tiles = (counts[e] + block - 1) / block;
+      for (int t = 0; t < tiles; t++) tile_expert[off / block + t] = e;
+      off += tiles * block;
+    }
+    offsets[num_experts] = off;
+    *num_tiles = off / block;
+    for (int t = off / block; t < max_tiles; t++) tile_expert[t] = -1;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < slots; i += blockDim.x) {
+    const int e = ids[i];
+    if (e >= 0 && e < num_experts) {
+      const int pos = offsets[e] + atomicAdd(&cursor[e], 1);
+      sorted_ids[pos] = i;
+      slot_pos[i] = pos;
+    } else {
+      slot_pos[i] = -1;
+    }
+  }
+  // padding: the tail of every expert's run and everything past the last run name no slot
+  for (int e = 0; e < num_experts; e++) {
+    const int from = offsets[e] + counts[e], to = offsets[e + 1];
+    for (int i = from + threadIdx.x; i < to; i += blockDim.x) sorted_ids[i] = slots;
+  }
+  for (int i = offsets[num_experts] + threadIdx.x; i < max_tiles * block; i += blockDim.x) sorted_ids[i] = slots;
+}
+
 }  // namespace mi355q
 
 using namespace mi355q;
+
+extern "C" int mi355q_moe_align_block_size(const int32_t* expert_ids, int slots, int num_experts, int block,
+                                           int32_t* sorted_ids, int32_t* tile_expert, int32_t* num_tiles,
+                                           int32_t* slot_pos, int max_tiles, mi355q_stream_t stream) {
+  MI355Q_REQUIRE(expert_ids && sorted_ids && tile_expert && num_tiles && slot_pos, "moe_align_block_size: null pointer");
+  MI355Q_REQUIRE(slots >= 0 && num_experts >= 1 && num_experts <= 4096 && block >= 1, "moe_align_block_size: bad arguments");
+  const long need = ((long)slots + (long)std::min(slots, num_experts) * (block - 1) + block - 1) / block;
+  MI355Q_REQUIRE(max_tiles >= need, "moe_align_block_size: room for %d tiles, %ld may be needed", max_tiles, need);
+  hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(1024), (3 * (size_t)num_experts + 1) * sizeof(int), (hipStream_t)stream,
+                     expert_ids, slots, num_experts, block, sorted_ids, tile_expert, num_tiles, slot_pos, max_tiles);
+  return check_launch("moe_align_kernel");
+}
 
 extern "C" int mi355q_topk_softmax(float* topk_weights, int32_t* topk_ids, const void* gating_output,
                                    int num_tokens, int num_experts, int topk, int renormalize,

@@ -1572,6 +1572,11 @@ struct MmParams {
   int M, N, K;
   int chunks, gchunks, cps, splits;
   int epi_silu;
+  // grouped (token-sorted) expert GEMM: row tile t multiplies with the weights of expert tile_expert[t]
+  // (negative: none) while t < *num_tiles; wp / scales / zc then hold all experts, these strides apart
+  const int* tile_expert;
+  const int* num_tiles;
+  size_t wp_estride, sc_estride;   // in u32x4 / in scale elements
 };
 
 template <typename DT>
@@ -1611,6 +1616,17 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 1) void w4a16_mm_kernel(const Mm
   const int c0 = blockIdx.z * p.cps, c1 = c0 + p.cps;
   const int groups = p.chunks / p.gchunks;
   const int srow = threadIdx.x >> 4, sseg = threadIdx.x & 15;
+  const u32x4* wp_e = p.wp;
+  const uint16_t* sc_e = p.scales;
+  const uint16_t* zc_e = p.zc;
+  if (p.tile_expert) {   // uniform over the workgroup: whole tiles leave before any barrier
+    if ((int)blockIdx.y >= *p.num_tiles) return;
+    const int e = p.tile_expert[blockIdx.y];
+    if (e < 0) return;
+    wp_e += (size_t)e * p.wp_estride;
+    sc_e += (size_t)e * p.sc_estride;
+    if constexpr (HAS_ZC) zc_e += (size_t)e * p.sc_estride;
+  }
 
   auto load_acts = [&](int c, u32x4 (&t)[RT]) {
 #pragma unroll
@@ -1628,7 +1644,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 1) void w4a16_mm_kernel(const Mm
     for (int j = 0; j < SPW; j++)
 #pragma unroll
       for (int pl = 0; pl < NS; pl++)
-        w[j * NS + pl] = p.wp[(((size_t)(strip0 + j) * p.chunks + c) * NS + pl) * 64 + lane];
+        w[j * NS + pl] = wp_e[(((size_t)(strip0 + j) * p.chunks + c) * NS + pl) * 64 + lane];
   };
   auto load_s = [&](int c, u32x2 (&sv)[CT], u32x2 (&zv)[CT]) {
     const int g = c / p.gchunks;
@@ -1637,8 +1653,8 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 1) void w4a16_mm_kernel(const Mm
 #pragma unroll
       for (int sub = 0; sub < NS; sub++) {
         const size_t off = ((size_t)(strip0 + j) * groups + g) * SW + QW * kq + 4 * sub;
-        sv[j * NS + sub] = *reinterpret_cast<const u32x2*>(p.scales + off);
-        if constexpr (HAS_ZC) zv[j * NS + sub] = *reinterpret_cast<const u32x2*>(p.zc + off);
+        sv[j * NS + sub] = *reinterpret_cast<const u32x2*>(sc_e + off);
+        if constexpr (HAS_ZC) zv[j * NS + sub] = *reinterpret_cast<const u32x2*>(zc_e + off);
       }
   };
   auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
@@ -2387,7 +2403,7 @@ extern "C" int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const
                      ((uintptr_t)c & 7) == 0 && ((uintptr_t)zc & 15) == 0 && ((uintptr_t)bias & 7) == 0,
                  "w4a16_mm: pointers must be 16-byte aligned");
   MI355Q_REQUIRE(!silu_pairs || bias == nullptr, "w4a16_mm: the SiLU-pair epilogue takes no bias");
-  MmParams p;
+  MmParams p{};
   p.x = (const uint16_t*)a; p.ldx = lda; p.wp = (const u32x4*)packed;
   p.scales = (const uint16_t*)scales; p.zc = (const uint16_t*)zc; p.bias = (const uint16_t*)bias;
   p.out = (uint16_t*)c; p.partial = nullptr;
@@ -2406,6 +2422,54 @@ extern "C" int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const
   if (mp.splits > 1) {
     MI355Q_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "w4a16_mm: K-slices need a 16-byte aligned workspace");
     if (workspace_bytes < mp.ws) return set_error(MI355Q_ENOSPACE, "w4a16_mm: workspace %zu B < %zu B", workspace_bytes, mp.ws);
+    p.partial = (float*)workspace;
+  }
+  return act_dtype == MI355Q_BF16 ? launch_mm<BF16>(p, mp, (hipStream_t)stream) : launch_mm<FP16>(p, mp, (hipStream_t)stream);
+}
+
+/* ---- grouped expert GEMM over token-sorted rows (MoE prompt batches) -------------- */
+extern "C" int mi355q_moe_grouped_block_rows(void) { return 16 * MM_RT; }
+
+extern "C" size_t mi355q_moe_w4a16_grouped_mm_workspace_bytes(int rows, int N, int K, int G, int tile) {
+  if (G <= 0) G = K;
+  if (rows <= 16 * 2 || N <= 0 || K <= 0) return 0;
+  const MmPlan mp = plan_mm(rows, N, K, G, tile);
+  return mp.ok ? mp.ws : 0;
+}
+
+extern "C" int mi355q_moe_w4a16_grouped_mm(const void* a, int lda, const void* packed, const void* scales,
+                                           const void* zc, const int* tile_expert, const int* num_tiles, void* c,
+                                           int rows, int num_experts, int N, int K, int G, int tile, int act_dtype,
+                                           int silu_pairs, void* workspace, size_t workspace_bytes,
+                                           mi355q_stream_t stream) {
+  if (int e = check_shape(K, N, G)) return e;
+  if (int e = check_tile(tile, K, G, N)) return e;
+  MI355Q_REQUIRE(act_dtype == MI355Q_BF16 || act_dtype == MI355Q_FP16, "moe_w4a16_grouped_mm: act_dtype must be bf16 or fp16");
+  if (rows == 0) return MI355Q_OK;
+  const int bm = 16 * MM_RT;
+  MI355Q_REQUIRE(a && packed && scales && c && tile_expert && num_tiles && num_experts > 0, "moe_w4a16_grouped_mm: bad arguments");
+  MI355Q_REQUIRE(rows > 0 && rows % bm == 0 && mm_rt(rows) == MM_RT,
+                 "moe_w4a16_grouped_mm: %d rows; whole tiles of %d rows (at least one) are expected", rows, bm);
+  MI355Q_REQUIRE(lda % 8 == 0 && lda >= K, "moe_w4a16_grouped_mm: row stride %d must be a multiple of 8 and cover the row", lda);
+  MI355Q_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)scales & 15) == 0 &&
+                     ((uintptr_t)c & 7) == 0 && ((uintptr_t)zc & 15) == 0,
+                 "moe_w4a16_grouped_mm: pointers must be 16-byte aligned");
+  const MmPlan mp = plan_mm(rows, N, K, G, tile);
+  MI355Q_REQUIRE(mp.ok, "moe_w4a16_grouped_mm: needs a group size that is a multiple of 128 and N a multiple of %d for strip width %d",
+                 tile == 112 ? 448 : 256, tile);
+  MmParams p{};
+  p.x = (const uint16_t*)a; p.ldx = lda; p.wp = (const u32x4*)packed;
+  p.scales = (const uint16_t*)scales; p.zc = (const uint16_t*)zc; p.bias = nullptr;
+  p.out = (uint16_t*)c; p.partial = nullptr;
+  p.M = rows; p.N = N; p.K = K; p.chunks = K / 128; p.gchunks = G / 128;
+  p.epi_silu = silu_pairs ? 1 : 0;
+  p.tile_expert = tile_expert; p.num_tiles = num_tiles;
+  p.wp_estride = (size_t)K * N / 32;            // K N / 2 bytes per expert
+  p.sc_estride = (size_t)(K / G) * N;
+  p.splits = mp.splits; p.cps = p.chunks / mp.splits;
+  if (mp.splits > 1) {
+    MI355Q_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "moe_w4a16_grouped_mm: K-slices need a 16-byte aligned workspace");
+    if (workspace_bytes < mp.ws) return set_error(MI355Q_ENOSPACE, "moe_w4a16_grouped_mm: workspace %zu B < %zu B", workspace_bytes, mp.ws);
     p.partial = (float*)workspace;
   }
   return act_dtype == MI355Q_BF16 ? launch_mm<BF16>(p, mp, (hipStream_t)stream) : launch_mm<FP16>(p, mp, (hipStream_t)stream);
@@ -2476,7 +2540,7 @@ extern "C" int mi355q_w4a16_mm_add_rms_norm(const void* a, int lda, const void* 
     if (e) return e;
     return mi355q_splitk_add_rms_norm(out, residual, r.partial, rp.splits, bias, norm_weight, epsilon, M, N, act_dtype, stream);
   }
-  MmParams p;
+  MmParams p{};
   p.x = (const uint16_t*)a; p.ldx = lda; p.wp = (const u32x4*)packed;
   p.scales = (const uint16_t*)scales; p.zc = (const uint16_t*)zc; p.bias = (const uint16_t*)bias;
   p.out = (uint16_t*)out; p.partial = nullptr;
@@ -2544,7 +2608,7 @@ extern "C" int mi355q_w4a16_mm_rope_and_cache(const void* a, int lda, const void
                  "w4a16_mm_rope_and_cache: pointers must be 16-byte aligned");
   MI355Q_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "w4a16_mm_rope_and_cache: K-slices need a 16-byte aligned workspace");
   if (workspace_bytes < mp.ws) return set_error(MI355Q_ENOSPACE, "w4a16_mm_rope_and_cache: workspace %zu B < %zu B", workspace_bytes, mp.ws);
-  MmParams p;
+  MmParams p{};
   p.x = (const uint16_t*)a; p.ldx = lda; p.wp = (const u32x4*)packed;
   p.scales = (const uint16_t*)scales; p.zc = (const uint16_t*)zc; p.bias = (const uint16_t*)bias;
   p.out = (uint16_t*)qkv; p.partial = (float*)workspace;

@@ -58,6 +58,11 @@ _SIGS = {
     "mi355q_topk_softmax": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_moe_w4a16_gemm": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_moe_align_block_size": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "mi355q_moe_grouped_block_rows": (c_int, []),
+    "mi355q_moe_w4a16_grouped_mm_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
+    "mi355q_moe_w4a16_grouped_mm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                            c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "mi355q_moe_sum": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_w8a16_gemm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_w8a16_dequantize": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),

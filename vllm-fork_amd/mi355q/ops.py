@@ -493,6 +493,58 @@ def moe_w4a16_gemm(x: torch.Tensor, w: PackedMoeW4, expert_ids: torch.Tensor, x_
     return out
 
 
+def moe_align_block_size(expert_ids: torch.Tensor, num_experts: int, block_size: int | None = None):
+    """ops.moe_align_block_size (vllm/_custom_ops.py:2237-2255) for the grouped expert GEMM: the slots
+    (`expert_ids` int32 [slots], negative = expert held elsewhere) sorted by expert, every expert's run padded
+    to whole tiles.  Returns (sorted_ids [max_tiles * block], tile_expert [max_tiles], num_tiles [1],
+    slot_pos [slots]); padding rows of sorted_ids hold `slots`."""
+    _need_cuda(expert_ids)
+    if expert_ids.dtype != torch.int32 or not expert_ids.is_contiguous():
+        raise RuntimeError("moe_align_block_size: expert_ids must be a contiguous int32 tensor")
+    L = _lib.lib()
+    block = block_size or L.mi355q_moe_grouped_block_rows()
+    slots = expert_ids.numel()
+    max_tiles = max(1, (slots + min(slots, num_experts) * (block - 1) + block - 1) // block)
+    dev = expert_ids.device
+    sorted_ids = torch.empty(max_tiles * block, dtype=torch.int32, device=dev)
+    tile_expert = torch.empty(max_tiles, dtype=torch.int32, device=dev)
+    num_tiles = torch.empty(1, dtype=torch.int32, device=dev)
+    slot_pos = torch.empty(slots, dtype=torch.int32, device=dev)
+    check(L.mi355q_moe_align_block_size(expert_ids.data_ptr(), slots, num_experts, block, sorted_ids.data_ptr(),
+                                        tile_expert.data_ptr(), num_tiles.data_ptr(), slot_pos.data_ptr(), max_tiles,
+                                        _stream()))
+    return sorted_ids, tile_expert, num_tiles, slot_pos
+
+
+def moe_grouped_mm_supported(w: PackedMoeW4) -> bool:
+    return _mm_supported(w.expert(0))
+
+
+def moe_w4a16_grouped_mm(x_sorted: torch.Tensor, w: PackedMoeW4, tile_expert: torch.Tensor, num_tiles: torch.Tensor,
+                         silu_pairs: bool = False) -> torch.Tensor:
+    """Row r of the result = x_sorted[r] @ dequant(expert tile_expert[r // block]) for the rows of the first
+    num_tiles tiles (the rest is left uninitialised).  Stands in for ops.moe_wna16_gemm
+    (vllm/_custom_ops.py:2307-2342) at prompt sizes, on rows sorted by `moe_align_block_size`."""
+    _need_cuda(x_sorted, w.packed, tile_expert, num_tiles)
+    if silu_pairs and not w.pair_halves:
+        raise RuntimeError("moe_w4a16_grouped_mm: silu_pairs needs experts repacked with pair_halves")
+    rows = x_sorted.shape[0]
+    if x_sorted.dim() != 2 or x_sorted.shape[1] != w.K or x_sorted.stride(1) != 1:
+        raise RuntimeError(f"moe_w4a16_grouped_mm: input must be [rows, {w.K}]")
+    L = _lib.lib()
+    if tile_expert.numel() * L.mi355q_moe_grouped_block_rows() != rows:
+        raise RuntimeError("moe_w4a16_grouped_mm: one tile_expert entry per row tile is expected")
+    out = torch.empty((rows, w.N // 2 if silu_pairs else w.N), dtype=x_sorted.dtype, device=x_sorted.device)
+    need = L.mi355q_moe_w4a16_grouped_mm_workspace_bytes(rows, w.N, w.K, w.G, w.tile)
+    ws = _workspace(x_sorted.device, need + COUNTER_BYTES) if need else None
+    check(L.mi355q_moe_w4a16_grouped_mm(x_sorted.data_ptr(), x_sorted.stride(0), w.packed.data_ptr(), w.scales.data_ptr(),
+                                        _ptr(w.zc), tile_expert.data_ptr(), num_tiles.data_ptr(), out.data_ptr(), rows,
+                                        w.E, w.N, w.K, w.G, w.tile, _dt(x_sorted), int(silu_pairs),
+                                        ws.data_ptr() + COUNTER_BYTES if ws is not None else None,
+                                        ws.numel() - COUNTER_BYTES if ws is not None else 0, _stream()))
+    return out
+
+
 def moe_sum(input: torch.Tensor, output: torch.Tensor, topk_weights: torch.Tensor | None = None) -> None:
     """ops.moe_sum(input [T, topk, H], output [T, H]) (vllm/_custom_ops.py:2228); with
     topk_weights (fp32 [T, topk]) the rows are weighted in fp32 before the sum."""

@@ -32,7 +32,7 @@ from .registry import QuantizationConfig, QuantizeMethodBase, register_quantizat
 #   prompt-sized batches outside graph capture: tokens grouped per expert on the host, dequantise +
 #     dense GEMM per expert (compute-bound there, so the unselected rows would not be free).
 ALL_EXPERTS_MAX_TOKENS = 64
-FORCE_ROUTE: str | None = None   # tests: "slots" | "all_experts" | "grouped"
+FORCE_ROUTE: str | None = None   # tests: "slots" | "all_experts" | "grouped" | "grouped_host"
 
 
 def convert_awq_tensor(tensor: torch.Tensor, tensor_type: str) -> torch.Tensor:
@@ -230,10 +230,12 @@ def fused_experts(x: torch.Tensor, w13: ops.PackedMoeW4, w2: ops.PackedMoeW4, to
         route = FORCE_ROUTE
     elif slots <= w13.E:
         route = "slots"
-    elif T <= ALL_EXPERTS_MAX_TOKENS or capturing:
+    elif T <= ALL_EXPERTS_MAX_TOKENS:
         route = "all_experts"
     else:
         route = "grouped"
+    if route == "grouped" and not (ops.moe_grouped_mm_supported(w13) and ops.moe_grouped_mm_supported(w2)):
+        route = "all_experts" if capturing else "grouped_host"   # layer shapes the tiled kernel does not take
     if route == "all_experts":
         E = w13.E
         ys = torch.empty((E + 1, T, H), dtype=x.dtype, device=x.device)
@@ -262,6 +264,24 @@ def fused_experts(x: torch.Tensor, w13: ops.PackedMoeW4, w2: ops.PackedMoeW4, to
             act = torch.empty((slots, w2.K), dtype=x.dtype, device=x.device)
             ops.silu_and_mul(act, h)
             y = ops.moe_w4a16_gemm(act, w2, ids, 1)
+    elif route == "grouped":
+        # token-sorted rows, one launch per projection over all experts (fused_experts_impl,
+        # fused_moe.py:1650-1850: moe_align_block_size, two grouped GEMMs, activation between them); no host
+        # round trip, so the route can be captured
+        sorted_ids, tile_expert, num_tiles, slot_pos = ops.moe_align_block_size(ids, w13.E)
+        src = torch.clamp(sorted_ids, max=slots - 1).long() // topk        # padding rows read some valid token
+        xs = x.index_select(0, src)
+        if w13.pair_halves:
+            act = ops.moe_w4a16_grouped_mm(xs, w13, tile_expert, num_tiles, silu_pairs=True)
+        else:
+            h = ops.moe_w4a16_grouped_mm(xs, w13, tile_expert, num_tiles)
+            act = torch.empty((h.shape[0], h.shape[1] // 2), dtype=x.dtype, device=x.device)
+            ops.silu_and_mul(act, h)
+        ys = ops.moe_w4a16_grouped_mm(act, w2, tile_expert, num_tiles)
+        held = slot_pos >= 0
+        y = ys.index_select(0, torch.clamp(slot_pos, min=0).long())        # back to slot order
+        if expert_map is not None:                                         # slots of experts held elsewhere add nothing
+            y = y * held.view(-1, 1).to(y.dtype)
     else:
         y = torch.zeros((slots, H), dtype=x.dtype, device=x.device)
         for e in ids.unique().tolist():
