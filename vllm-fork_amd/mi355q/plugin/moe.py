@@ -22,16 +22,20 @@ from .parallel import (get_tensor_model_parallel_rank, get_tensor_model_parallel
                        tensor_model_parallel_all_reduce)
 from .registry import QuantizationConfig, QuantizeMethodBase, register_quantization_config
 
-# Three routes for the routed experts:
+# Routes for the routed experts:
 #   slots (tokens x topk) <= local experts: every slot streams its own expert's weights (decode GEMV
 #     with the expert indirection); no token sort, capturable;
 #   more slots, up to ALL_EXPERTS_MAX_TOKENS tokens: every local expert runs over ALL tokens (its
 #     weights are read once, and at these sizes a projection costs what its weights cost to
 #     stream, so rows an expert was not selected for are free); the combine picks each token's
 #     selected rows.  No data-dependent shapes: capturable;
-#   prompt-sized batches outside graph capture: tokens grouped per expert on the host, dequantise +
-#     dense GEMM per expert (compute-bound there, so the unselected rows would not be free).
-ALL_EXPERTS_MAX_TOKENS = 64
+#   larger batches ("grouped"): slots sorted by expert on the device, every expert's run padded to whole
+#     row tiles, one grouped GEMM launch per projection over all experts (the tiled W4A16 kernel with a
+#     tile -> expert indirection); no host round trip, capturable;
+#   "grouped_host", only for layer shapes the tiled kernel does not take, outside graph capture: tokens
+#     grouped per expert on the host, dequantise + dense GEMM per expert.
+ALL_EXPERTS_MAX_TOKENS = 8      # measured on a Mixtral-sized layer: 332 us at 9 tokens against 350-370 us token-sorted
+ALL_EXPERTS_MAX_TOKENS_UNSORTED = 64   # layers the token-sorted kernel does not take
 FORCE_ROUTE: str | None = None   # tests: "slots" | "all_experts" | "grouped" | "grouped_host"
 
 
@@ -235,7 +239,8 @@ def fused_experts(x: torch.Tensor, w13: ops.PackedMoeW4, w2: ops.PackedMoeW4, to
     else:
         route = "grouped"
     if route == "grouped" and not (ops.moe_grouped_mm_supported(w13) and ops.moe_grouped_mm_supported(w2)):
-        route = "all_experts" if capturing else "grouped_host"   # layer shapes the tiled kernel does not take
+        # layer shapes the tiled kernel does not take
+        route = "all_experts" if capturing or T <= ALL_EXPERTS_MAX_TOKENS_UNSORTED else "grouped_host"
     if route == "all_experts":
         E = w13.E
         ys = torch.empty((E + 1, T, H), dtype=x.dtype, device=x.device)
