@@ -1964,7 +1964,14 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw) {
   if (G % 128 || K % 128 || sw % 16) return mp;
   const int ns = sw / 16;
   if (ns != 1 && ns != 2 && ns != 4 && ns != 7) return mp;
-  const int spw = ns == 1 ? 4 : (ns == 2 ? 2 : 1);
+  // Strips per wave: a workgroup covers 4 spw strips.  Narrower workgroups (MI355Q_MM_SPW) need fewer
+  // K-slices to fill the chip and measured 10-25 % faster as stand-alone GEMMs on the short-K 8B layers
+  // up to about a thousand rows, but inside the prompt pass they lose it again: with fewer slices the
+  // projections leave the fused slice-merge kernels (residual add + RMSNorm, RoPE + cache write) for the
+  // two-launch sequences (TTFT(128) 5.36 -> 5.56 ms), so the wide forms stay the default.
+  int spw = ns == 1 ? 4 : (ns == 2 ? 2 : 1);
+  while (spw > 1 && N % (4 * spw * sw)) spw >>= 1;
+  if (const int o = env_int("MI355Q_MM_SPW", 0); o > 0 && o <= 4 / ns && (o & (o - 1)) == 0) spw = o;   // experiments
   const int bw = 4 * spw * sw;
   if (N % bw) return mp;
   const int chunks = K / 128;
@@ -1976,6 +1983,7 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw) {
     for (int f = 7; f >= 3; f -= 2)
       if (chunks % (s * f) == 0 && chunks / (s * f) >= 2 && tiles * s * f <= 512) { s *= f; break; }
   }
+  if (const int o = env_int("MI355Q_MM_SPLITS", 0); o > 0 && chunks % o == 0) s = o;                  // experiments
   mp.ok = true; mp.ns = ns; mp.spw = spw; mp.splits = s;
   mp.ws = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
   return mp;
@@ -1992,10 +2000,11 @@ static int launch_mm(const MmParams& p, const MmPlan& mp, hipStream_t stream, bo
     else hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, RT_, false>), grid, block, 0, stream, p);        \
   }
 #define MI355Q_MM(NS_, SPW_)                                                                              \
-  if (mp.ns == NS_) {                                                                                     \
+  if (mp.ns == NS_ && mp.spw == SPW_) {                                                                   \
     if (rt == 2) MI355Q_MM_RT(NS_, SPW_, 2) else MI355Q_MM_RT(NS_, SPW_, MM_RT)                            \
   }
-  MI355Q_MM(1, 4) else MI355Q_MM(2, 2) else MI355Q_MM(4, 1) else MI355Q_MM(7, 1)
+  MI355Q_MM(1, 4) else MI355Q_MM(1, 2) else MI355Q_MM(1, 1) else MI355Q_MM(2, 2) else MI355Q_MM(2, 1)
+  else MI355Q_MM(4, 1) else MI355Q_MM(7, 1)
 #undef MI355Q_MM
 #undef MI355Q_MM_RT
   if (int e = check_launch("w4a16_mm_kernel")) return e;
