@@ -1966,9 +1966,9 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw) {
   if (ns != 1 && ns != 2 && ns != 4 && ns != 7) return mp;
   // Strips per wave: a workgroup covers 4 spw strips.  Narrower workgroups (MI355Q_MM_SPW) need fewer
   // K-slices to fill the chip and measured 10-25 % faster as stand-alone GEMMs on the short-K 8B layers
-  // up to about a thousand rows, but inside the prompt pass they lose it again: with fewer slices the
-  // projections leave the fused slice-merge kernels (residual add + RMSNorm, RoPE + cache write) for the
-  // two-launch sequences (TTFT(128) 5.36 -> 5.56 ms), so the wide forms stay the default.
+  // up to about a thousand rows, but inside the prompt pass, where the slice sums are merged by the fused
+  // consumers (residual add + RMSNorm, RoPE + cache write), the whole pass measured slower with them
+  // (TTFT(128) 5.36 -> 5.56 ms), so the wide forms stay the default.
   int spw = ns == 1 ? 4 : (ns == 2 ? 2 : 1);
   while (spw > 1 && N % (4 * spw * sw)) spw >>= 1;
   if (const int o = env_int("MI355Q_MM_SPW", 0); o > 0 && o <= 4 / ns && (o & (o - 1)) == 0) spw = o;   // experiments
