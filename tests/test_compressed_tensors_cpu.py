@@ -154,17 +154,58 @@ def fp8_config(strategy="channel", input_activations=None, block=None):
     ("channel", {"num_bits": 8, "type": "float", "symmetric": True, "strategy": "token", "dynamic": True}, False),
     ("block", None, False),
 ])
-def test_fp8_checkpoints_resolve_to_the_weight_only_scheme(strategy, act, static):
+def test_fp8_checkpoints_resolve_to_the_weight_only_scheme(strategy, act, static, monkeypatch):
+    monkeypatch.setenv("MI355Q_FP8_LINEAR", "w8a16")
     cfg = make(fp8_config(strategy, act, [128, 128] if strategy == "block" else None))
     lin = MergedColumnParallelLinear(512, [256, 256], bias=False, params_dtype=torch.bfloat16, quant_config=cfg,
                                      prefix="model.layers.0.mlp.gate_up_proj", return_bias=False)
     s = lin.scheme
-    assert isinstance(s, CompressedTensorsW8A16Fp8) and s.is_static_input_scheme == static
+    assert type(s) is CompressedTensorsW8A16Fp8 and s.is_static_input_scheme == static
     assert lin.weight.dtype == torch.float8_e4m3fn and lin.weight.shape == (512, 512)
     want = {"channel": (512, 1), "tensor": (2,), "block": (4, 4)}[strategy]
     assert lin.weight_scale.shape == want
     assert hasattr(lin, "input_scale") == static
     assert cfg.has_blocked_weights() == (strategy == "block")
+
+
+@pytest.mark.parametrize("strategy,dynamic", [("tensor", False), ("tensor", True), ("channel", False), ("channel", True)])
+def test_fp8_w8a8_checkpoints_resolve_to_the_activation_quantising_scheme(strategy, dynamic, monkeypatch):
+    """compressed_tensors.py:831-846: an fp8 W8A8 checkpoint with tensor / channel weight scales takes the
+    scheme that quantises activations; fused per-tensor shards end on one scale (the largest), their fp8
+    values rewritten for it (fp8_utils.py:1321-1346)."""
+    from mi355q.plugin.compressed_tensors import CompressedTensorsW8A8Fp8
+    monkeypatch.delenv("MI355Q_FP8_LINEAR", raising=False)
+    act = {"num_bits": 8, "type": "float", "symmetric": True, "strategy": "token" if dynamic else "tensor",
+           "dynamic": dynamic}
+    cfg = make(fp8_config(strategy, act, None))
+    lin = MergedColumnParallelLinear(64, [32, 48], bias=False, params_dtype=torch.bfloat16, quant_config=cfg,
+                                     prefix="model.layers.0.mlp.gate_up_proj", return_bias=False)
+    assert type(lin.scheme) is CompressedTensorsW8A8Fp8 and lin.scheme.is_static_input_scheme == (not dynamic)
+    g = torch.Generator().manual_seed(3)
+    ws, scales = [], [0.02, 0.05]
+    for i, width in enumerate([32, 48]):
+        w8 = (torch.randn((width, 64), generator=g) * 20).to(torch.float8_e4m3fn)
+        lin.weight_loader(lin.weight, w8, i)
+        if strategy == "tensor":
+            lin.weight_loader(lin.weight_scale, torch.tensor(scales[i]), i)
+            ws.append(w8.float() * scales[i])
+        else:
+            sc = 0.01 + 0.02 * torch.rand((width, 1), generator=g)
+            lin.weight_loader(lin.weight_scale, sc, i)
+            ws.append(w8.float() * sc)
+        if not dynamic:
+            lin.weight_loader(lin.input_scale, torch.tensor(0.1 * (i + 1)), i)
+    lin.process_weights_after_loading()
+    assert lin.weight_scale.shape == ((1,) if strategy == "tensor" else (80,))
+    if strategy == "tensor":
+        assert float(lin.weight_scale) == pytest.approx(0.05)
+    # the stored values times the stored scale still are the checkpoint's weights (to fp8 rounding at the new scale)
+    deq = lin.weight.float() * lin.weight_scale.reshape(-1, 1)
+    torch.testing.assert_close(deq, torch.cat(ws), rtol=0.07, atol=0.05 * 2 ** -9)
+    if dynamic:
+        assert lin.input_scale is None
+    else:
+        assert lin.input_scale.shape == (1,) and float(lin.input_scale) == pytest.approx(0.2)
 
 
 def test_schemes_outside_the_weight_only_path_are_named_and_refused():

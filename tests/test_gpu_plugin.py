@@ -662,10 +662,11 @@ def test_compressed_tensors_actorder_group():
 
 
 @pytest.mark.parametrize("strategy", ["tensor", "channel", "block"])
-def test_compressed_tensors_fp8_weight_only(strategy):
-    """float-quantized fp8 weights (a W8A8 checkpoint with dynamic activation arguments included): served
-    weight-only, x @ (fp8(w) * scale)^T."""
+def test_compressed_tensors_fp8_weight_only(strategy, monkeypatch):
+    """float-quantized fp8 weights (a W8A8 checkpoint with dynamic activation arguments included) under
+    MI355Q_FP8_LINEAR=w8a16: served weight-only, x @ (fp8(w) * scale)^T."""
     from mi355q.plugin import CompressedTensorsConfig
+    monkeypatch.setenv("MI355Q_FP8_LINEAR", "w8a16")
     rng = np.random.default_rng(25)
     hidden, inter, T = 512, 768, 2
     w_args = {"num_bits": 8, "type": "float", "symmetric": True, "strategy": strategy, "dynamic": False}
@@ -704,3 +705,65 @@ def test_compressed_tensors_fp8_weight_only(strategy):
     got = gu(to_dev(x))
     np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=1e-2)
     assert (to_bits(got) == ref).mean() > 0.97
+
+
+@pytest.mark.parametrize("T", [3, 200])
+@pytest.mark.parametrize("strategy,dynamic", [("tensor", False), ("tensor", True), ("channel", False),
+                                              ("channel", True)])
+def test_compressed_tensors_fp8_w8a8(strategy, dynamic, T, monkeypatch):
+    """float-quantized fp8 W8A8 checkpoint (schemes/compressed_tensors_w8a8_fp8.py:60-207): activations
+    quantised with the checkpoint's largest input_scale (static) or one scale per token (dynamic), fused
+    per-tensor shards requantised to the largest weight scale, then the scaled fp8 x fp8 product.  Checked
+    against the same steps on the CPU."""
+    from mi355q.plugin import CompressedTensorsConfig
+    from mi355q.plugin.compressed_tensors import CompressedTensorsW8A8Fp8
+    monkeypatch.delenv("MI355Q_FP8_LINEAR", raising=False)
+    rng = np.random.default_rng(41)
+    hidden, inter = 512, 768
+    w_args = {"num_bits": 8, "type": "float", "symmetric": True, "strategy": strategy, "dynamic": False}
+    act = {"num_bits": 8, "type": "float", "symmetric": True, "strategy": "token" if dynamic else "tensor",
+           "dynamic": dynamic}
+    cfg = CompressedTensorsConfig.from_config({
+        "quant_method": "compressed-tensors", "format": "float-quantized", "ignore": ["lm_head"],
+        "config_groups": {"group_0": {"targets": ["Linear"], "weights": w_args, "input_activations": act}}})
+    cfg.packed_modules_mapping = _CT_FUSED
+    with torch.device(DEV):
+        gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16,
+                                        quant_config=cfg, prefix="model.layers.0.mlp.gate_up_proj", return_bias=False)
+    assert type(gu.scheme) is CompressedTensorsW8A8Fp8
+    ws, ss, in_scales = [], [], [0.02, 0.035]
+    for i in range(2):
+        w8 = orc.f32_to_e4m3((rng.standard_normal((inter, hidden)) * 30).astype(np.float32))
+        gu.weight_loader(gu.weight, torch.from_numpy(w8).view(torch.float8_e4m3fn), i)
+        if strategy == "tensor":
+            s = np.float32(0.002 * (i + 1))
+            gu.weight_loader(gu.weight_scale, torch.tensor(s), i)
+            ss.append(s)
+        else:
+            s = (0.001 + 0.002 * rng.random((inter, 1))).astype(np.float32)
+            gu.weight_loader(gu.weight_scale, torch.from_numpy(s), i)
+            ss.append(s.reshape(-1))
+        if not dynamic:
+            gu.weight_loader(gu.input_scale, torch.tensor(in_scales[i]), i)
+        ws.append(w8)
+    gu.process_weights_after_loading()
+    x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    # CPU restatement of the same steps
+    if strategy == "tensor":
+        smax = np.float32(max(ss))
+        deq = [(torch.from_numpy(w).view(torch.float8_e4m3fn).to(torch.float16) * s).float().numpy()
+               for w, s in zip(ws, ss)]                                                   # through fp16
+        wq = np.concatenate([orc.static_scaled_fp8_quant(d, np.array([smax], np.float32), None, orc.FP32) for d in deq])
+        assert np.array_equal(gu.weight.data.view(torch.uint8).cpu().numpy(), wq)
+        sb = np.array([smax], np.float32)
+    else:
+        wq, sb = np.concatenate(ws), np.concatenate(ss)
+    if dynamic:
+        xq, sa = orc.dynamic_per_token_scaled_fp8_quant(x)
+    else:
+        sa = np.array([max(in_scales)], np.float32)
+        xq = orc.static_scaled_fp8_quant(x, sa)
+    ref = orc.fp8_scaled_mm(xq, wq, sa, sb)
+    got = to_bits(gu(to_dev(x)))
+    np.testing.assert_allclose(f32(got), f32(ref), rtol=1e-2, atol=1e-2)
+    assert (got == ref).mean() > 0.97

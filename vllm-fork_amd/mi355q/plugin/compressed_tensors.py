@@ -1,16 +1,19 @@
-"""compressed-tensors checkpoints (`quant_method: "compressed-tensors"`), weight-only schemes.
+"""compressed-tensors checkpoints (`quant_method: "compressed-tensors"`): weight-only schemes and fp8 W8A8.
 
 Mirrors vllm/model_executor/layers/quantization/compressed_tensors/ of the reference:
 `CompressedTensorsConfig` (compressed_tensors.py:82-968: config groups -> target scheme map, ignore
 list, per-layer scheme resolution), `CompressedTensorsLinearMethod` (:971-1019),
 `CompressedTensorsKVCacheMethod` (:1022-1072), the target / ignore matching helpers (utils.py:40-239)
-and the two weight-only schemes that reach this package's kernels:
+and the schemes that reach this package's kernels:
 
   CompressedTensorsWNA16     (schemes/compressed_tensors_wNa16.py:51-257)  pack-quantized INT4 / INT8,
                               group or channel scales, optional zero points and activation ordering
                               -> MPLinearKernel chooser -> MI355X W4A16 / W8A16 kernels
   CompressedTensorsW8A16Fp8  (schemes/compressed_tensors_w8a16_fp8.py:38-160)  fp8 e4m3 weights with
                               tensor / channel / block scales -> fp8 weight-only GEMM
+  CompressedTensorsW8A8Fp8   (schemes/compressed_tensors_w8a8_fp8.py:60-207)  fp8 weights with tensor / channel
+                              scales, activations quantised per tensor (static) or per token (dynamic)
+                              -> scaled fp8 x fp8 product
 
 The `compressed_tensors` library itself (pydantic models `QuantizationArgs`, enums) is a
 third-party dependency that is absent from the reference tree; the fields the reference reads from it
@@ -19,12 +22,14 @@ signed values are offset by 2^(bits-1) to unsigned and packed least-significant-
 the input dimension (`weight_packed` int32 [N, K*bits/32]), zero points along the output dimension
 (`weight_zero_point` int32 [N*bits/32, K/G]); scales are `weight_scale` [N, K/G].
 
-Schemes that quantize activations (W8A8 int8, W4A8, nvfp4 / mxfp4 / mxfp8) are a different arithmetic
-path and are not built: asking for their scheme raises NotImplementedError naming the scheme.  An fp8
-W8A8 checkpoint is served weight-only (its activation scale is loaded and dropped), which is what the
-reference does on devices without fp8 matrix support (compressed_tensors.py:831-837).
+Other schemes that quantize activations (W8A8 int8, W4A8, nvfp4 / mxfp4 / mxfp8) are a different arithmetic
+path and are not built: asking for their scheme raises NotImplementedError naming the scheme.  A
+block-quantised fp8 W8A8 checkpoint (and any fp8 W8A8 checkpoint under MI355Q_FP8_LINEAR=w8a16) is served
+weight-only (its activation scale is loaded and dropped), which is what the reference does on devices
+without fp8 matrix support (compressed_tensors.py:831-837).
 """
 import math
+import os
 import re
 from dataclasses import dataclass, field
 from fractions import Fraction
@@ -360,6 +365,58 @@ class CompressedTensorsW8A16Fp8(CompressedTensorsScheme):
                               layer.mi355q_scale_block, bias)
 
 
+class CompressedTensorsW8A8Fp8(CompressedTensorsW8A16Fp8):
+    """schemes/compressed_tensors_w8a8_fp8.py:60-207 for the tensor and channel weight strategies: activations
+    are quantised to fp8 -- with the checkpoint's input_scale (static: the largest over fused shards, :193-194)
+    or with one run-time scale per token (dynamic: kFp8DynamicTokenSym, :47-50) -- and the product runs as a
+    scaled fp8 x fp8 matrix product.  Per-tensor weights of a fused layer are requantised to their largest scale
+    (process_fp8_weight_tensor_strategy, fp8_utils.py:1321-1346); per-channel weights keep their scales
+    (process_fp8_weight_channel_strategy, :1349-1364).  Checkpoint tensors are those of the weight-only
+    scheme."""
+
+    def __init__(self, weight_quant: QuantizationArgs, is_static_input_scheme: bool):
+        super().__init__(weight_quant, is_static_input_scheme)
+        if self.strategy == "block":
+            raise ValueError("block-quantised fp8 weights run weight-only (CompressedTensorsW8A16Fp8)")
+
+    def process_weights_after_loading(self, layer) -> None:
+        from .fp8 import FP8_MAX
+        w, ws = layer.weight.data, layer.weight_scale.data.to(torch.float32)
+        if self.strategy == "tensor":
+            ws = ws.reshape(-1)
+            max_s = ws.max()
+            if ws.numel() > 1 and ws[-1] > torch.finfo(torch.float8_e4m3fn).min:   # one scale per shard was loaded
+                start = 0
+                for idx, width in enumerate(layer.logical_widths):
+                    if width:
+                        dq = w[start:start + width].to(torch.float16) * ws[idx]
+                        if w.is_cuda:
+                            q, _ = ops.scaled_fp8_quant(dq.contiguous(), scale=max_s.reshape(1))
+                        else:
+                            q = (dq.float() * (1.0 / max_s)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+                        w[start:start + width] = q
+                    start += width
+            ws = max_s.reshape(1)
+        else:
+            ws = ws.reshape(-1)
+        _set(layer, "weight", w)
+        _set(layer, "weight_scale", ws.contiguous())
+        if self.is_static_input_scheme:
+            _set(layer, "input_scale", layer.input_scale.data.to(torch.float32).max().reshape(1).contiguous())
+        else:
+            _set(layer, "input_scale", None)
+        layer.mi355q_scale_block = None
+
+    def apply_weights(self, layer, x, bias=None):
+        x2 = x.reshape(-1, x.shape[-1])
+        if self.is_static_input_scheme:
+            xq, xs = ops.scaled_fp8_quant(x2, scale=layer.input_scale.data)
+        else:
+            xq, xs = ops.scaled_fp8_quant(x2, use_per_token_if_dynamic=True)
+        out = ops.fp8_scaled_mm(xq, layer.weight.data, x.dtype, xs, layer.weight_scale.data, bias)
+        return out.reshape(x.shape[:-1] + (out.shape[-1],))
+
+
 # -- config ----------------------------------------------------------------------------------------
 @register_quantization_config("compressed-tensors")
 class CompressedTensorsConfig(QuantizationConfig):
@@ -508,7 +565,11 @@ class CompressedTensorsConfig(QuantizationConfig):
                                           actorder=weight_quant.actorder, layer_name=layer_name)
         if is_activation_quantization_format(format):
             if self._is_fp8_w8a8(weight_quant, input_quant):
-                # served weight-only; the activation arguments of the checkpoint are ignored after loading
+                # block-quantised weights (their activations would need per-token-group scales) and
+                # MI355Q_FP8_LINEAR=w8a16 are served weight-only: the activation arguments are then ignored
+                if weight_quant.strategy != "block" and os.environ.get("MI355Q_FP8_LINEAR", "w8a8") == "w8a8":
+                    return CompressedTensorsW8A8Fp8(weight_quant=weight_quant,
+                                                    is_static_input_scheme=not input_quant.dynamic)
                 return CompressedTensorsW8A16Fp8(weight_quant=weight_quant,
                                                  is_static_input_scheme=not input_quant.dynamic)
             if self._is_fp8_w8a16(weight_quant, input_quant):
