@@ -1753,6 +1753,217 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 1) void w4a16_mm_kernel(const Mm
 }
 
 // ---------------------------------------------------------------------------
+// The same tile ([64 rows] x [4 waves x CT subtiles], one K-slice) with every operand of a chunk --
+// activations, weight planes, scales -- brought in by LDS-DMA (global_load ... lds) into a ring of
+// S stages, S - 1 chunks ahead of use.  The register-prefetching kernel above holds one chunk in
+// flight per wave at one wave per SIMD, and a chunk's arithmetic (about 1.5 us) is shorter than a
+// loaded memory round trip, so it runs at the speed of the memory latency; the ring holds 100+ KB
+// in flight per CU without a single register.
+//   stage image: A [64 rows][256 B], the 16-byte piece p of row r at position p ^ (r & 15) (conflict-
+//   free ds_read_b128 of MFMA fragments; LDS-DMA writes lane-linear, so the source address carries
+//   the permutation); W [wave][CT planes][1 KiB] lane-linear, read back as it was written; scales
+//   [wave][strip][256 B] (one 4-byte piece per lane), read as the 8 bytes of a lane's 4 channels.
+// LDS-DMA completes in issue order with the other vector-memory operations of the wave, so "stage c
+// has landed" is s_waitcnt vmcnt(number of operations issued after it); there are no other
+// vector-memory operations inside the loop.  Arithmetic and rounding as in the kernel above.
+// ---------------------------------------------------------------------------
+template <int NS, int SPW, bool HAS_ZC>
+struct MmRing {
+  static constexpr int CT = NS * SPW;
+  static constexpr bool SPLIT_SUB = NS == 7;          // wave halves split the strip's subtiles, else the rows
+  static constexpr int BM = SPLIT_SUB ? 64 : 128;
+  static constexpr int A_OPS = BM / 32, W_OPS = (CT + 1) / 2, SC_OPS = SPW * (HAS_ZC ? 2 : 1);
+  static constexpr int OPS = A_OPS + W_OPS + SC_OPS;  // LDS-DMA operations per wave and stage
+  static constexpr int A_BYTES = BM * 256, W_BYTES = 4 * CT * 1024, SC_BYTES = 4 * SPW * 256;
+  static constexpr int STAGE = A_BYTES + W_BYTES + SC_BYTES * (HAS_ZC ? 2 : 1);
+  static constexpr int S = (160 * 1024) / STAGE >= 4 ? 4 : (160 * 1024) / STAGE;
+  static constexpr int LDS = S * STAGE;
+};
+
+template <int N>
+__device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Eight waves, two per SIMD, so that one wave's vector work (4-bit expansion, scale step) overlaps the
+// other's matrix instructions: waves 0-3 and 4-7 take the same strips and either the two 64-row halves of
+// a 128-row tile (CT <= 4) or, on 112-wide strips, subtiles 0-3 and 4-6 of the same 64 rows.
+template <typename DT, int NS, int SPW, bool HAS_ZC>
+__global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p) {
+  using R = MmRing<NS, SPW, HAS_ZC>;
+  constexpr int CT = R::CT, SW = 16 * NS, RT = 4, BM = R::BM, S = R::S;
+  constexpr int CTW = R::SPLIT_SUB ? 4 : CT;          // subtiles a wave owns (the upper half of a 112-wide strip: 3)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: LDS-DMA targets stay in SGPRs
+  const int wq = wave & 3, wh = wave >> 2;
+  const int kq = lane >> 4, ml = lane & 15;
+  const int strip0 = (blockIdx.x * 4 + wq) * SPW;
+  const int row0 = blockIdx.y * BM;
+  const int rbase = R::SPLIT_SUB ? 0 : 64 * wh;       // this wave's rows inside the tile
+  const int sub0 = R::SPLIT_SUB ? 4 * wh : 0;         // this wave's first subtile
+  const int nsub = R::SPLIT_SUB ? (wh ? 3 : 4) : CT;
+  const int c0 = blockIdx.z * p.cps, c1 = c0 + p.cps;
+  const int groups = p.chunks / p.gchunks;
+  const u32x4* wp_e = p.wp;
+  const uint16_t* sc_e = p.scales;
+  const uint16_t* zc_e = p.zc;
+  if (p.tile_expert) {   // uniform over the workgroup: whole tiles leave before any barrier
+    if ((int)blockIdx.y >= *p.num_tiles) return;
+    const int e = p.tile_expert[blockIdx.y];
+    if (e < 0) return;
+    wp_e += (size_t)e * p.wp_estride;
+    sc_e += (size_t)e * p.sc_estride;
+    if constexpr (HAS_ZC) zc_e += (size_t)e * p.sc_estride;
+  }
+  // sources of this lane's pieces of a stage (chunk 0; a chunk is 256 bytes further along a row)
+  const uint16_t* asrc[R::A_OPS];
+#pragma unroll
+  for (int i = 0; i < R::A_OPS; i++) {
+    const int r = 4 * (R::A_OPS * wave + i) + (lane >> 4);
+    asrc[i] = p.x + (size_t)min(row0 + r, p.M - 1) * p.ldx + 8 * ((lane & 15) ^ (r & 15));
+  }
+  const int sdw = min(lane, SW / 2 - 1);   // 4-byte piece of a strip's SW scales
+  auto issue = [&](int c, int slot) {
+    unsigned char* st = ring + slot * R::STAGE;
+#pragma unroll
+    for (int i = 0; i < R::A_OPS; i++)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[i] + (size_t)c * 128),
+                                       (void __attribute__((address_space(3)))*)(st + (R::A_OPS * wave + i) * 1024), 16, 0, 0);
+    // the planes of the quad's strips are shared out between its two waves (an odd count: the last twice)
+#pragma unroll
+    for (int i = 0; i < R::W_OPS; i++) {
+      const int pi = min(2 * i + wh, CT - 1), j = pi / NS, pl = pi % NS;
+      __builtin_amdgcn_global_load_lds(
+          (const void __attribute__((address_space(1)))*)(wp_e + (((size_t)(strip0 + j) * p.chunks + c) * NS + pl) * 64 + lane),
+          (void __attribute__((address_space(3)))*)(st + R::A_BYTES + (wq * CT + pi) * 1024), 16, 0, 0);
+    }
+    const int g = c / p.gchunks;
+#pragma unroll
+    for (int j = 0; j < SPW; j++) {   // both waves of a quad (same bytes, same place)
+      const size_t off = ((size_t)(strip0 + j) * groups + g) * SW + 2 * sdw;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(sc_e + off),
+                                       (void __attribute__((address_space(3)))*)(st + R::A_BYTES + R::W_BYTES + (wq * SPW + j) * 256), 4, 0, 0);
+      if constexpr (HAS_ZC)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(zc_e + off),
+                                         (void __attribute__((address_space(3)))*)(st + R::A_BYTES + R::W_BYTES + R::SC_BYTES + (wq * SPW + j) * 256), 4, 0, 0);
+    }
+  };
+  auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
+  auto hi = [](uint32_t u) { return DT::to_f32((uint16_t)(u >> 16)); };
+
+#pragma unroll
+  for (int i = 0; i < S - 1; i++)
+    if (c0 + i < c1) issue(c0 + i, i);
+
+  f32x4 tot[RT][CTW];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int ct = 0; ct < CTW; ct++) tot[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (x & mask) | magic as ONE instruction needs both constants in registers (gfx9 three-operand encodings
+  // take no literal; with literals the compiler emits an AND and an OR): 7 instead of 11 per packed dword
+  uint32_t magic_v = DT::int4_magic, nib_mask = 0x000F000Fu;
+  asm volatile("" : "+v"(magic_v), "+s"(nib_mask));
+  auto expand = [&](uint32_t w) {
+    u32x4 r;
+    r[0] = (w & nib_mask) | magic_v;
+    r[1] = ((w >> 4) & nib_mask) | magic_v;
+    r[2] = ((w >> 8) & nib_mask) | magic_v;
+    r[3] = ((w >> 12) & nib_mask) | magic_v;
+    return r;
+  };
+
+  int slot = 0;
+  for (int c = c0; c < c1; c++) {
+    // stages after c already issued: min(S - 2, c1 - 1 - c); each is OPS operations per wave
+    const int ahead = min(S - 2, c1 - 1 - c);
+    if (S >= 4 && ahead >= 2) wait_vm<2 * R::OPS>();
+    else if (S >= 3 && ahead == 1) wait_vm<R::OPS>();
+    else wait_vm<0>();
+    // A bare barrier: __syncthreads() carries a fence that waits for EVERY outstanding memory operation,
+    // the younger stages included.  This wave's pieces of stage c have landed (the wait above), its LDS
+    // reads of chunk c - 1 have returned (their data was consumed), so the barrier alone makes stage c
+    // complete for every wave and chunk c - 1's slot free.
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int free_slot = slot == 0 ? S - 1 : slot - 1;
+    if (c + S - 1 < c1) issue(c + S - 1, free_slot);
+    const unsigned char* st = ring + slot * R::STAGE;
+    slot = slot == S - 1 ? 0 : slot + 1;
+
+    u32x4 bf[4][RT];
+    f32x4 acc1[RT];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) {
+        bf[ks][rt] = *reinterpret_cast<const u32x4*>(st + (rbase + 16 * rt + ml) * 256 + 16 * ((4 * ks + kq) ^ ml));
+        acc1[rt] = mfma16<DT>(ones, bf[ks][rt], ks == 0 ? zero4 : acc1[rt]);
+      }
+    u32x4 wc[CT];
+#pragma unroll
+    for (int i = 0; i < CT; i++)
+      wc[i] = *reinterpret_cast<const u32x4*>(st + R::A_BYTES + (wq * CT + i) * 1024 + 16 * lane);
+    // lane (kq, ml): rows 16 rt + ml, channels QW kq + 4 sub + r of each strip
+#pragma unroll
+    for (int ct = 0; ct < CTW; ct++) {
+      if (R::SPLIT_SUB && ct >= nsub) break;           // wave-uniform
+      const int j = R::SPLIT_SUB ? 0 : ct / NS;
+      const int sub = R::SPLIT_SUB ? sub0 + ct : ct % NS;   // run-time only for the split strips
+      const int soff = (wq * SPW + j) * 256 + 8 * (NS * kq + sub);
+      const u32x2 sv = *reinterpret_cast<const u32x2*>(st + R::A_BYTES + R::W_BYTES + soff);
+      u32x2 zv = u32x2{0u, 0u};
+      if constexpr (HAS_ZC) zv = *reinterpret_cast<const u32x2*>(st + R::A_BYTES + R::W_BYTES + R::SC_BYTES + soff);
+      f32x4 acc[RT];
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        uint32_t w;
+        if constexpr (R::SPLIT_SUB) {   // dword ks * 7 + sub of the strip's 28; wh selects between two fixed ones
+          const int e0 = ks * NS + ct, e1 = ks * NS + 4 + ct;
+          const uint32_t w0 = wc[e0 >> 2][e0 & 3], w1 = wc[min(e1, 27) >> 2][min(e1, 27) & 3];
+          w = wh ? w1 : w0;
+        } else {
+          const int e = ks * NS + sub;
+          w = wc[j * NS + (e >> 2)][e & 3];
+        }
+        const u32x4 wf = expand(w);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) acc[rt] = mfma16<DT>(wf, bf[ks][rt], ks == 0 ? zero4 : acc[rt]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float s = (r & 1) ? hi(sv[r >> 1]) : lo(sv[r >> 1]);
+        float z;
+        if constexpr (HAS_ZC) z = (r & 1) ? hi(zv[r >> 1]) : lo(zv[r >> 1]);
+        else z = DT::int4_bias + 8.0f;
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+          tot[rt][ct][r] = __builtin_fmaf(s, __builtin_fmaf(-z, acc1[rt][r], acc[rt][r]), tot[rt][ct][r]);
+      }
+    }
+  }
+
+  constexpr int QW = 4 * NS;
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    const int row = row0 + rbase + 16 * rt + ml;
+    if (row >= p.M) continue;
+#pragma unroll
+    for (int ct = 0; ct < CTW; ct++) {
+      if (R::SPLIT_SUB && ct >= nsub) break;
+      const int j = R::SPLIT_SUB ? 0 : ct / NS;
+      const int sub = R::SPLIT_SUB ? sub0 + ct : ct % NS;
+      const int n = SW * (strip0 + j) + QW * kq + 4 * sub;
+      if (p.splits > 1)
+        *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.z * p.M + row) * p.N + n) = tot[rt][ct];
+      else
+        mm_store<DT>(p, row, n, tot[rt][ct]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // 17..32 rows per pass (decode batches), one workgroup per strip: the weights of a strip are streamed
 // ONCE, by eight waves that split K, exactly as the decode kernel above streams them -- the tiled
 // kernel re-reads every strip per 32-row block and needs K-slices plus a second kernel to fill the
@@ -1953,13 +2164,25 @@ static inline int mm_rt(int M) {
   return M <= rt2_max ? 2 : MM_RT;
 }
 
+// The LDS-ring form of the tiled kernel serves 33+ rows on the full-width workgroup forms (4+ subtiles per
+// wave quad); its row tile is 128 except on 112-wide strips.  The grouped expert GEMM sorts rows into blocks
+// of 64, so there it applies to 112-wide strips only.  Measured on the 8B layers (us, register-prefetch form
+// -> ring form): 2048 rows down 353 -> 271, o 105 -> 82, gate_up 665 -> 629, qkv 150 -> 154; 512 rows down
+// 105 -> 86; 128 rows gate_up 63.6 -> 57.6, but qkv 33.9 -> 37.7 and o 23.0 -> 24.2 on a single 128-row tile.
+static inline bool mm_ring_form(int ns, int spw, bool grouped, int M) {
+  static const int use_ring = env_int("MI355Q_MM_RING", 1);
+  static const int rows128_min = env_int("MI355Q_MM_RING_MIN", 129);   // one 128-row tile alone needs more K-slices: slower
+  if (!use_ring || ns * spw < 4) return false;
+  return ns == 7 || (!grouped && M >= rows128_min);
+}
+
 struct MmPlan {
   bool ok;
   int ns, spw, splits;
   size_t ws;   // bytes of fp32 partial tiles
 };
 
-static MmPlan plan_mm(int M, int N, int K, int G, int sw) {
+static MmPlan plan_mm(int M, int N, int K, int G, int sw, bool grouped = false) {
   MmPlan mp{false, 0, 0, 1, 0};
   if (G % 128 || K % 128 || sw % 16) return mp;
   const int ns = sw / 16;
@@ -1975,7 +2198,7 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw) {
   const int bw = 4 * spw * sw;
   if (N % bw) return mp;
   const int chunks = K / 128;
-  const int bm = 16 * mm_rt(M);
+  const int bm = (mm_rt(M) == MM_RT && ns != 7 && mm_ring_form(ns, spw, grouped, M)) ? 128 : 16 * mm_rt(M);
   const long tiles = (long)(N / bw) * ((M + bm - 1) / bm);
   int s = 1;
   while (tiles * s < 200 && s < 16 && chunks % (s * 2) == 0 && chunks / (s * 2) >= 2) s *= 2;
@@ -1994,19 +2217,33 @@ static int launch_mm(const MmParams& p, const MmPlan& mp, hipStream_t stream, bo
   const int bw = 4 * mp.spw * 16 * mp.ns;
   const int rt = mm_rt(p.M);
   dim3 grid(p.N / bw, (p.M + 16 * rt - 1) / (16 * rt), p.splits), block(256);
+  const int rbm = mp.ns == 7 ? 64 : 128;
+  dim3 rgrid(p.N / bw, (p.M + rbm - 1) / rbm, p.splits);
 #define MI355Q_MM_RT(NS_, SPW_, RT_)                                                                       \
   {                                                                                                       \
     if (p.zc) hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, RT_, true>), grid, block, 0, stream, p);    \
     else hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, RT_, false>), grid, block, 0, stream, p);        \
   }
+#define MI355Q_MM_RING(NS_, SPW_)                                                                          \
+  {                                                                                                       \
+    if (p.zc)                                                                                             \
+      hipLaunchKernelGGL((w4a16_mm_ring_kernel<DT, NS_, SPW_, true>), rgrid, dim3(512),                     \
+                         (MmRing<NS_, SPW_, true>::LDS), stream, p);                                        \
+    else                                                                                                  \
+      hipLaunchKernelGGL((w4a16_mm_ring_kernel<DT, NS_, SPW_, false>), rgrid, dim3(512),                    \
+                         (MmRing<NS_, SPW_, false>::LDS), stream, p);                                       \
+  }
 #define MI355Q_MM(NS_, SPW_)                                                                              \
   if (mp.ns == NS_ && mp.spw == SPW_) {                                                                   \
-    if (rt == 2) MI355Q_MM_RT(NS_, SPW_, 2) else MI355Q_MM_RT(NS_, SPW_, MM_RT)                            \
+    if (rt == 2) MI355Q_MM_RT(NS_, SPW_, 2)                                                                \
+    else if (mm_ring_form(NS_, SPW_, p.tile_expert != nullptr, p.M)) MI355Q_MM_RING(NS_, SPW_)                  \
+    else MI355Q_MM_RT(NS_, SPW_, MM_RT)                                                                    \
   }
   MI355Q_MM(1, 4) else MI355Q_MM(1, 2) else MI355Q_MM(1, 1) else MI355Q_MM(2, 2) else MI355Q_MM(2, 1)
   else MI355Q_MM(4, 1) else MI355Q_MM(7, 1)
 #undef MI355Q_MM
 #undef MI355Q_MM_RT
+#undef MI355Q_MM_RING
   if (int e = check_launch("w4a16_mm_kernel")) return e;
   if (p.splits > 1 && reduce) {
     const size_t items = (size_t)p.M * (p.N >> 2);
@@ -2442,7 +2679,7 @@ extern "C" int mi355q_moe_grouped_block_rows(void) { return 16 * MM_RT; }
 extern "C" size_t mi355q_moe_w4a16_grouped_mm_workspace_bytes(int rows, int N, int K, int G, int tile) {
   if (G <= 0) G = K;
   if (rows <= 16 * 2 || N <= 0 || K <= 0) return 0;
-  const MmPlan mp = plan_mm(rows, N, K, G, tile);
+  const MmPlan mp = plan_mm(rows, N, K, G, tile, true);
   return mp.ok ? mp.ws : 0;
 }
 
@@ -2463,7 +2700,7 @@ extern "C" int mi355q_moe_w4a16_grouped_mm(const void* a, int lda, const void* p
   MI355Q_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)scales & 15) == 0 &&
                      ((uintptr_t)c & 7) == 0 && ((uintptr_t)zc & 15) == 0,
                  "moe_w4a16_grouped_mm: pointers must be 16-byte aligned");
-  const MmPlan mp = plan_mm(rows, N, K, G, tile);
+  const MmPlan mp = plan_mm(rows, N, K, G, tile, true);
   MI355Q_REQUIRE(mp.ok, "moe_w4a16_grouped_mm: needs a group size that is a multiple of 128 and N a multiple of %d for strip width %d",
                  tile == 112 ? 448 : 256, tile);
   MmParams p{};
