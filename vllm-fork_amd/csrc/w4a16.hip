@@ -1767,17 +1767,24 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 1) void w4a16_mm_kernel(const Mm
 // has landed" is s_waitcnt vmcnt(number of operations issued after it); there are no other
 // vector-memory operations inside the loop.  Arithmetic and rounding as in the kernel above.
 // ---------------------------------------------------------------------------
-template <int NS, int SPW, bool HAS_ZC>
+// What the two wave halves (waves 0-3, 4-7) of a workgroup split between them
+constexpr int RING_ROWS = 0;   // the two 64-row halves of a 128-row tile
+constexpr int RING_SUB = 1;    // subtiles 0-3 / 4-6 of a 112-wide strip, same 64 rows
+constexpr int RING_K = 2;      // even / odd chunks of the same 64-row tile, summed through LDS at the end
+
+template <int NS, int SPW, bool HAS_ZC, int MODE>
 struct MmRing {
   static constexpr int CT = NS * SPW;
-  static constexpr bool SPLIT_SUB = NS == 7;          // wave halves split the strip's subtiles, else the rows
-  static constexpr int BM = SPLIT_SUB ? 64 : 128;
-  static constexpr int A_OPS = BM / 32, W_OPS = (CT + 1) / 2, SC_OPS = SPW * (HAS_ZC ? 2 : 1);
+  static constexpr bool SPLIT_SUB = MODE == RING_SUB, SPLIT_K = MODE == RING_K;
+  static constexpr int BM = MODE == RING_ROWS ? 128 : 64;
+  static constexpr int A_OPS = SPLIT_K ? 4 : BM / 32, W_OPS = SPLIT_K ? CT : (CT + 1) / 2, SC_OPS = SPW * (HAS_ZC ? 2 : 1);
   static constexpr int OPS = A_OPS + W_OPS + SC_OPS;  // LDS-DMA operations per wave and stage
   static constexpr int A_BYTES = BM * 256, W_BYTES = 4 * CT * 1024, SC_BYTES = 4 * SPW * 256;
-  static constexpr int STAGE = A_BYTES + W_BYTES + SC_BYTES * (HAS_ZC ? 2 : 1);
+  static constexpr int HALF = A_BYTES + W_BYTES + SC_BYTES * (HAS_ZC ? 2 : 1);   // one chunk's image
+  static constexpr int STAGE = SPLIT_K ? 2 * HALF : HALF;                       // a stage of the K-split form holds two chunks
   static constexpr int S = (160 * 1024) / STAGE >= 4 ? 4 : (160 * 1024) / STAGE;
   static constexpr int LDS = S * STAGE;
+  static_assert(!SPLIT_K || 4 * 16 * 64 * 16 <= LDS, "the final sum of the two K halves goes through the ring");
 };
 
 template <int N>
@@ -1785,10 +1792,11 @@ __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) :
 
 // Eight waves, two per SIMD, so that one wave's vector work (4-bit expansion, scale step) overlaps the
 // other's matrix instructions: waves 0-3 and 4-7 take the same strips and either the two 64-row halves of
-// a 128-row tile (CT <= 4) or, on 112-wide strips, subtiles 0-3 and 4-6 of the same 64 rows.
-template <typename DT, int NS, int SPW, bool HAS_ZC>
+// a 128-row tile, or subtiles 0-3 and 4-6 of the same 64 rows (112-wide strips), or the even and the odd
+// chunks of the same 64-row tile (few rows: half as many K-slices, i.e. partial tiles, fill the chip).
+template <typename DT, int NS, int SPW, bool HAS_ZC, int MODE>
 __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p) {
-  using R = MmRing<NS, SPW, HAS_ZC>;
+  using R = MmRing<NS, SPW, HAS_ZC, MODE>;
   constexpr int CT = R::CT, SW = 16 * NS, RT = 4, BM = R::BM, S = R::S;
   constexpr int CTW = R::SPLIT_SUB ? 4 : CT;          // subtiles a wave owns (the upper half of a 112-wide strip: 3)
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
@@ -1798,9 +1806,12 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
   const int kq = lane >> 4, ml = lane & 15;
   const int strip0 = (blockIdx.x * 4 + wq) * SPW;
   const int row0 = blockIdx.y * BM;
-  const int rbase = R::SPLIT_SUB ? 0 : 64 * wh;       // this wave's rows inside the tile
+  const int rbase = MODE == RING_ROWS ? 64 * wh : 0;  // this wave's rows inside the tile
   const int sub0 = R::SPLIT_SUB ? 4 * wh : 0;         // this wave's first subtile
   const int nsub = R::SPLIT_SUB ? (wh ? 3 : 4) : CT;
+  constexpr int CSTEP = R::SPLIT_K ? 2 : 1;           // chunks per stage
+  const int cofs = R::SPLIT_K ? wh : 0;               // this wave's chunk of a stage
+  const int aw = R::SPLIT_K ? wq : wave;              // which share of the stage's rows / planes this wave fetches
   const int c0 = blockIdx.z * p.cps, c1 = c0 + p.cps;
   const int groups = p.chunks / p.gchunks;
   const u32x4* wp_e = p.wp;
@@ -1818,20 +1829,22 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
   const uint16_t* asrc[R::A_OPS];
 #pragma unroll
   for (int i = 0; i < R::A_OPS; i++) {
-    const int r = 4 * (R::A_OPS * wave + i) + (lane >> 4);
+    const int r = 4 * (R::A_OPS * aw + i) + (lane >> 4);
     asrc[i] = p.x + (size_t)min(row0 + r, p.M - 1) * p.ldx + 8 * ((lane & 15) ^ (r & 15));
   }
   const int sdw = min(lane, SW / 2 - 1);   // 4-byte piece of a strip's SW scales
-  auto issue = [&](int c, int slot) {
-    unsigned char* st = ring + slot * R::STAGE;
+  auto issue = [&](int c_in, int slot) {
+    const int c = c_in + cofs;
+    unsigned char* st = ring + slot * R::STAGE + cofs * R::HALF;
 #pragma unroll
     for (int i = 0; i < R::A_OPS; i++)
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[i] + (size_t)c * 128),
-                                       (void __attribute__((address_space(3)))*)(st + (R::A_OPS * wave + i) * 1024), 16, 0, 0);
-    // the planes of the quad's strips are shared out between its two waves (an odd count: the last twice)
+                                       (void __attribute__((address_space(3)))*)(st + (R::A_OPS * aw + i) * 1024), 16, 0, 0);
+    // the planes of the quad's strips are shared out between its two waves (an odd count: the last twice);
+    // in the K-split form every wave fetches all planes of its own chunk
 #pragma unroll
     for (int i = 0; i < R::W_OPS; i++) {
-      const int pi = min(2 * i + wh, CT - 1), j = pi / NS, pl = pi % NS;
+      const int pi = R::SPLIT_K ? i : min(2 * i + wh, CT - 1), j = pi / NS, pl = pi % NS;
       __builtin_amdgcn_global_load_lds(
           (const void __attribute__((address_space(1)))*)(wp_e + (((size_t)(strip0 + j) * p.chunks + c) * NS + pl) * 64 + lane),
           (void __attribute__((address_space(3)))*)(st + R::A_BYTES + (wq * CT + pi) * 1024), 16, 0, 0);
@@ -1852,7 +1865,7 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
 
 #pragma unroll
   for (int i = 0; i < S - 1; i++)
-    if (c0 + i < c1) issue(c0 + i, i);
+    if (c0 + CSTEP * i < c1) issue(c0 + CSTEP * i, i);
 
   f32x4 tot[RT][CTW];
 #pragma unroll
@@ -1875,9 +1888,9 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
   };
 
   int slot = 0;
-  for (int c = c0; c < c1; c++) {
-    // stages after c already issued: min(S - 2, c1 - 1 - c); each is OPS operations per wave
-    const int ahead = min(S - 2, c1 - 1 - c);
+  for (int c = c0; c < c1; c += CSTEP) {
+    // stages after this one already issued: min(S - 2, stages left); each is OPS operations per wave
+    const int ahead = min(S - 2, (c1 - CSTEP - c) / CSTEP);
     if (S >= 4 && ahead >= 2) wait_vm<2 * R::OPS>();
     else if (S >= 3 && ahead == 1) wait_vm<R::OPS>();
     else wait_vm<0>();
@@ -1888,8 +1901,8 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const int free_slot = slot == 0 ? S - 1 : slot - 1;
-    if (c + S - 1 < c1) issue(c + S - 1, free_slot);
-    const unsigned char* st = ring + slot * R::STAGE;
+    if (c + CSTEP * (S - 1) < c1) issue(c + CSTEP * (S - 1), free_slot);
+    const unsigned char* st = ring + slot * R::STAGE + cofs * R::HALF;
     slot = slot == S - 1 ? 0 : slot + 1;
 
     u32x4 bf[4][RT];
@@ -1944,6 +1957,23 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
     }
   }
 
+  if constexpr (R::SPLIT_K) {   // odd-chunk sums join the even-chunk sums through the (now idle) ring
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f32x4* red = reinterpret_cast<f32x4*>(ring) + (size_t)wq * (RT * CT) * 64 + lane;
+    if (wh) {
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) red[(rt * CT + ct) * 64] = tot[rt][ct];
+    }
+    __syncthreads();
+    if (wh) return;
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) tot[rt][ct] += red[(rt * CT + ct) * 64];
+  }
   constexpr int QW = 4 * NS;
 #pragma unroll
   for (int rt = 0; rt < RT; rt++) {
@@ -2169,11 +2199,16 @@ static inline int mm_rt(int M) {
 // of 64, so there it applies to 112-wide strips only.  Measured on the 8B layers (us, register-prefetch form
 // -> ring form): 2048 rows down 353 -> 271, o 105 -> 82, gate_up 665 -> 629, qkv 150 -> 154; 512 rows down
 // 105 -> 86; 128 rows gate_up 63.6 -> 57.6, but qkv 33.9 -> 37.7 and o 23.0 -> 24.2 on a single 128-row tile.
-static inline bool mm_ring_form(int ns, int spw, bool grouped, int M) {
+// Returns the form (RING_ROWS / RING_SUB / RING_K) or -1 for the register-prefetch kernel.  cps = chunks per
+// K-slice when known (the K-split form takes them in pairs), else 0.
+static inline int mm_ring_form(int ns, int spw, bool grouped, int M, int cps) {
   static const int use_ring = env_int("MI355Q_MM_RING", 1);
   static const int rows128_min = env_int("MI355Q_MM_RING_MIN", 129);   // one 128-row tile alone needs more K-slices: slower
-  if (!use_ring || ns * spw < 4) return false;
-  return ns == 7 || (!grouped && M >= rows128_min);
+  static const int use_ksplit = env_int("MI355Q_MM_RING_K", 1);
+  if (!use_ring || ns * spw < 4) return -1;
+  if (ns == 7) return RING_SUB;
+  if (!grouped && M >= rows128_min) return RING_ROWS;
+  return use_ksplit && cps % 2 == 0 ? RING_K : -1;
 }
 
 struct MmPlan {
@@ -2198,11 +2233,19 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw, bool grouped = false) 
   const int bw = 4 * spw * sw;
   if (N % bw) return mp;
   const int chunks = K / 128;
-  const int bm = (mm_rt(M) == MM_RT && ns != 7 && mm_ring_form(ns, spw, grouped, M)) ? 128 : 16 * mm_rt(M);
+  const int bm = (mm_rt(M) == MM_RT && mm_ring_form(ns, spw, grouped, M, 0) == RING_ROWS) ? 128 : 16 * mm_rt(M);
   const long tiles = (long)(N / bw) * ((M + bm - 1) / bm);
+  // K-slices until about 200 workgroups exist.  The K-split ring form runs eight waves on a tile: from 120
+  // workgroups on it prefers slices of 8+ chunks to more workgroups (measured at 128 rows: qkv 30.2 -> 23.8 us
+  // with 4 instead of 8 slices, o 21.4 -> 20.7; down_proj, whose slices stay long, keeps its 8: 33.4 vs 43.4).
+  const bool ksplit = mm_rt(M) == MM_RT && mm_ring_form(ns, spw, grouped, M, 0) == RING_K;
+  const long want = 200;
   int s = 1;
-  while (tiles * s < 200 && s < 16 && chunks % (s * 2) == 0 && chunks / (s * 2) >= 2) s *= 2;
-  if (tiles * s < 200) {   // odd factors of the chunk count (K = 14336 = 128 * 112 = 128 * 16 * 7)
+  while (tiles * s < want && s < 16 && chunks % (s * 2) == 0 && chunks / (s * 2) >= 2) {
+    if (ksplit && tiles * s >= 120 && chunks / (s * 2) < 8) break;
+    s *= 2;
+  }
+  if (tiles * s < want) {   // odd factors of the chunk count (K = 14336 = 128 * 112 = 128 * 16 * 7)
     for (int f = 7; f >= 3; f -= 2)
       if (chunks % (s * f) == 0 && chunks / (s * f) >= 2 && tiles * s * f <= 512) { s *= f; break; }
   }
@@ -2212,38 +2255,48 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw, bool grouped = false) 
   return mp;
 }
 
+template <typename DT, int NS, int SPW, int MODE>
+static void launch_mm_ring_mode(const MmParams& p, int bw, hipStream_t stream) {
+  using R0 = MmRing<NS, SPW, false, MODE>;
+  using R1 = MmRing<NS, SPW, true, MODE>;
+  dim3 grid(p.N / bw, (p.M + R0::BM - 1) / R0::BM, p.splits), block(512);
+  if (p.zc) hipLaunchKernelGGL((w4a16_mm_ring_kernel<DT, NS, SPW, true, MODE>), grid, block, R1::LDS, stream, p);
+  else hipLaunchKernelGGL((w4a16_mm_ring_kernel<DT, NS, SPW, false, MODE>), grid, block, R0::LDS, stream, p);
+}
+
+template <typename DT, int NS, int SPW>
+static void launch_mm_ring(const MmParams& p, int bw, int form, hipStream_t stream) {
+  if constexpr (NS * SPW >= 4) {
+    if constexpr (NS == 7) {
+      launch_mm_ring_mode<DT, NS, SPW, RING_SUB>(p, bw, stream);
+    } else {
+      if (form == RING_K) launch_mm_ring_mode<DT, NS, SPW, RING_K>(p, bw, stream);
+      else launch_mm_ring_mode<DT, NS, SPW, RING_ROWS>(p, bw, stream);
+    }
+  }
+}
+
 template <typename DT>
 static int launch_mm(const MmParams& p, const MmPlan& mp, hipStream_t stream, bool reduce = true) {
   const int bw = 4 * mp.spw * 16 * mp.ns;
   const int rt = mm_rt(p.M);
   dim3 grid(p.N / bw, (p.M + 16 * rt - 1) / (16 * rt), p.splits), block(256);
-  const int rbm = mp.ns == 7 ? 64 : 128;
-  dim3 rgrid(p.N / bw, (p.M + rbm - 1) / rbm, p.splits);
+  const int ring = mm_ring_form(mp.ns, mp.spw, p.tile_expert != nullptr, p.M, p.cps);
 #define MI355Q_MM_RT(NS_, SPW_, RT_)                                                                       \
   {                                                                                                       \
     if (p.zc) hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, RT_, true>), grid, block, 0, stream, p);    \
     else hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, RT_, false>), grid, block, 0, stream, p);        \
   }
-#define MI355Q_MM_RING(NS_, SPW_)                                                                          \
-  {                                                                                                       \
-    if (p.zc)                                                                                             \
-      hipLaunchKernelGGL((w4a16_mm_ring_kernel<DT, NS_, SPW_, true>), rgrid, dim3(512),                     \
-                         (MmRing<NS_, SPW_, true>::LDS), stream, p);                                        \
-    else                                                                                                  \
-      hipLaunchKernelGGL((w4a16_mm_ring_kernel<DT, NS_, SPW_, false>), rgrid, dim3(512),                    \
-                         (MmRing<NS_, SPW_, false>::LDS), stream, p);                                       \
-  }
 #define MI355Q_MM(NS_, SPW_)                                                                              \
   if (mp.ns == NS_ && mp.spw == SPW_) {                                                                   \
     if (rt == 2) MI355Q_MM_RT(NS_, SPW_, 2)                                                                \
-    else if (mm_ring_form(NS_, SPW_, p.tile_expert != nullptr, p.M)) MI355Q_MM_RING(NS_, SPW_)                  \
+    else if (ring >= 0 && NS_ * SPW_ >= 4) launch_mm_ring<DT, NS_, SPW_>(p, bw, ring, stream);             \
     else MI355Q_MM_RT(NS_, SPW_, MM_RT)                                                                    \
   }
   MI355Q_MM(1, 4) else MI355Q_MM(1, 2) else MI355Q_MM(1, 1) else MI355Q_MM(2, 2) else MI355Q_MM(2, 1)
   else MI355Q_MM(4, 1) else MI355Q_MM(7, 1)
 #undef MI355Q_MM
 #undef MI355Q_MM_RT
-#undef MI355Q_MM_RING
   if (int e = check_launch("w4a16_mm_kernel")) return e;
   if (p.splits > 1 && reduce) {
     const size_t items = (size_t)p.M * (p.N >> 2);
