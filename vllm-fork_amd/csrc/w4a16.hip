@@ -2200,15 +2200,27 @@ static inline int mm_rt(int M) {
 // -> ring form): 2048 rows down 353 -> 271, o 105 -> 82, gate_up 665 -> 629, qkv 150 -> 154; 512 rows down
 // 105 -> 86; 128 rows gate_up 63.6 -> 57.6, but qkv 33.9 -> 37.7 and o 23.0 -> 24.2 on a single 128-row tile.
 // Returns the form (RING_ROWS / RING_SUB / RING_K) or -1 for the register-prefetch kernel.  cps = chunks per
-// K-slice when known (the K-split form takes them in pairs), else 0.
-static inline int mm_ring_form(int ns, int spw, bool grouped, int M, int cps) {
+// K-slice when known (the K-split form takes them in pairs), else 0; colblocks = N / workgroup width.
+// Rows or K between the wave halves: a 128-row tile takes about 1.85 x the time of a K-split 64-row tile
+// (measured on the 8B layers at 2048 rows), so the choice is which grid wastes less of its last round of 256
+// workgroups -- 2048 rows: down / o 16 x 16 tiles of 128 rows = one round (255 us against 278 K-split), qkv 24 x 16
+// = 1.5 rounds (146 us against 121 K-split in three full rounds).
+static inline int mm_ring_form(int ns, int spw, bool grouped, int M, int cps, int colblocks) {
   static const int use_ring = env_int("MI355Q_MM_RING", 1);
-  static const int rows128_min = env_int("MI355Q_MM_RING_MIN", 129);   // one 128-row tile alone needs more K-slices: slower
   static const int use_ksplit = env_int("MI355Q_MM_RING_K", 1);
+  static const int force_rows_min = env_int("MI355Q_MM_RING_MIN", 0);   // experiments: 128-row tiles from this many rows on
   if (!use_ring || ns * spw < 4) return -1;
   if (ns == 7) return RING_SUB;
-  if (!grouped && M >= rows128_min) return RING_ROWS;
-  return use_ksplit && cps % 2 == 0 ? RING_K : -1;
+  const bool k_ok = use_ksplit && cps % 2 == 0;
+  if (grouped) return k_ok ? RING_K : -1;
+  const long tiles_r = (long)colblocks * ((M + 127) / 128);
+  const long rounds_r = (tiles_r + 255) / 256, last_r = tiles_r % 256;
+  const long rounds_k = ((long)colblocks * ((M + 63) / 64) + 255) / 256;
+  // ... and only when the 128-row grid's last round is (nearly) full: qkv at 1024 rows, 192 tiles, 92 us against 80
+  const bool rows = force_rows_min > 0 ? M >= force_rows_min
+                                       : (M > 128 && rounds_r * 185 < rounds_k * 100 && (last_r == 0 || last_r >= 230));
+  if (rows || (!k_ok && M > 128)) return RING_ROWS;
+  return k_ok ? RING_K : -1;
 }
 
 struct MmPlan {
@@ -2233,12 +2245,12 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw, bool grouped = false) 
   const int bw = 4 * spw * sw;
   if (N % bw) return mp;
   const int chunks = K / 128;
-  const int bm = (mm_rt(M) == MM_RT && mm_ring_form(ns, spw, grouped, M, 0) == RING_ROWS) ? 128 : 16 * mm_rt(M);
+  const int bm = (mm_rt(M) == MM_RT && mm_ring_form(ns, spw, grouped, M, 0, N / bw) == RING_ROWS) ? 128 : 16 * mm_rt(M);
   const long tiles = (long)(N / bw) * ((M + bm - 1) / bm);
   // K-slices until about 200 workgroups exist.  The K-split ring form runs eight waves on a tile: from 120
   // workgroups on it prefers slices of 8+ chunks to more workgroups (measured at 128 rows: qkv 30.2 -> 23.8 us
   // with 4 instead of 8 slices, o 21.4 -> 20.7; down_proj, whose slices stay long, keeps its 8: 33.4 vs 43.4).
-  const bool ksplit = mm_rt(M) == MM_RT && mm_ring_form(ns, spw, grouped, M, 0) == RING_K;
+  const bool ksplit = mm_rt(M) == MM_RT && mm_ring_form(ns, spw, grouped, M, 0, N / bw) == RING_K;
   const long want = 200;
   int s = 1;
   while (tiles * s < want && s < 16 && chunks % (s * 2) == 0 && chunks / (s * 2) >= 2) {
@@ -2281,7 +2293,7 @@ static int launch_mm(const MmParams& p, const MmPlan& mp, hipStream_t stream, bo
   const int bw = 4 * mp.spw * 16 * mp.ns;
   const int rt = mm_rt(p.M);
   dim3 grid(p.N / bw, (p.M + 16 * rt - 1) / (16 * rt), p.splits), block(256);
-  const int ring = mm_ring_form(mp.ns, mp.spw, p.tile_expert != nullptr, p.M, p.cps);
+  const int ring = mm_ring_form(mp.ns, mp.spw, p.tile_expert != nullptr, p.M, p.cps, p.N / bw);
 #define MI355Q_MM_RT(NS_, SPW_, RT_)                                                                       \
   {                                                                                                       \
     if (p.zc) hipLaunchKernelGGL((w4a16_mm_kernel<DT, NS_, SPW_, RT_, true>), grid, block, 0, stream, p);    \
