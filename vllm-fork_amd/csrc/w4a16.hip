@@ -1777,9 +1777,9 @@ struct MmRing {
   static constexpr int CT = NS * SPW;
   static constexpr bool SPLIT_SUB = MODE == RING_SUB, SPLIT_K = MODE == RING_K;
   static constexpr int BM = MODE == RING_ROWS ? 128 : 64;
-  static constexpr int A_OPS = SPLIT_K ? 4 : BM / 32, W_OPS = SPLIT_K ? CT : (CT + 1) / 2, SC_OPS = SPW * (HAS_ZC ? 2 : 1);
+  static constexpr int A_OPS = SPLIT_K ? 4 : BM / 32, W_OPS = SPLIT_K ? CT : (CT + 1) / 2, SC_OPS = HAS_ZC ? 2 : 1;
   static constexpr int OPS = A_OPS + W_OPS + SC_OPS;  // LDS-DMA operations per wave and stage
-  static constexpr int A_BYTES = BM * 256, W_BYTES = 4 * CT * 1024, SC_BYTES = 4 * SPW * 256;
+  static constexpr int A_BYTES = BM * 256, W_BYTES = 4 * CT * 1024, SC_BYTES = 4 * 256;
   static constexpr int HALF = A_BYTES + W_BYTES + SC_BYTES * (HAS_ZC ? 2 : 1);   // one chunk's image
   static constexpr int STAGE = SPLIT_K ? 2 * HALF : HALF;                       // a stage of the K-split form holds two chunks
   static constexpr int S = (160 * 1024) / STAGE >= 4 ? 4 : (160 * 1024) / STAGE;
@@ -1832,7 +1832,8 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
     const int r = 4 * (R::A_OPS * aw + i) + (lane >> 4);
     asrc[i] = p.x + (size_t)min(row0 + r, p.M - 1) * p.ldx + 8 * ((lane & 15) ^ (r & 15));
   }
-  const int sdw = min(lane, SW / 2 - 1);   // 4-byte piece of a strip's SW scales
+  // scales of the quad's SPW strips in ONE operation: lane l fetches 4-byte piece l % (SW/2) of strip l / (SW/2)
+  const int sj = min(lane / (SW / 2), SPW - 1), sdw = lane % (SW / 2);
   auto issue = [&](int c_in, int slot) {
     const int c = c_in + cofs;
     unsigned char* st = ring + slot * R::STAGE + cofs * R::HALF;
@@ -1850,14 +1851,13 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
           (void __attribute__((address_space(3)))*)(st + R::A_BYTES + (wq * CT + pi) * 1024), 16, 0, 0);
     }
     const int g = c / p.gchunks;
-#pragma unroll
-    for (int j = 0; j < SPW; j++) {   // both waves of a quad (same bytes, same place)
-      const size_t off = ((size_t)(strip0 + j) * groups + g) * SW + 2 * sdw;
+    {   // both waves of a quad (same bytes, same place)
+      const size_t off = ((size_t)(strip0 + sj) * groups + g) * SW + 2 * sdw;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(sc_e + off),
-                                       (void __attribute__((address_space(3)))*)(st + R::A_BYTES + R::W_BYTES + (wq * SPW + j) * 256), 4, 0, 0);
+                                       (void __attribute__((address_space(3)))*)(st + R::A_BYTES + R::W_BYTES + wq * 256), 4, 0, 0);
       if constexpr (HAS_ZC)
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(zc_e + off),
-                                         (void __attribute__((address_space(3)))*)(st + R::A_BYTES + R::W_BYTES + R::SC_BYTES + (wq * SPW + j) * 256), 4, 0, 0);
+                                         (void __attribute__((address_space(3)))*)(st + R::A_BYTES + R::W_BYTES + R::SC_BYTES + wq * 256), 4, 0, 0);
     }
   };
   auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
@@ -1918,13 +1918,20 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
 #pragma unroll
     for (int i = 0; i < CT; i++)
       wc[i] = *reinterpret_cast<const u32x4*>(st + R::A_BYTES + (wq * CT + i) * 1024 + 16 * lane);
+    // symmetric weights: the products start from -(bias + 8) a1 instead of zero, which leaves one
+    // multiply-add per output for the scale step (same value as s (acc - z a1) up to the order of two roundings)
+    f32x4 cinit[RT];
+    if constexpr (!HAS_ZC) {
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) cinit[rt] = acc1[rt] * (-(DT::int4_bias + 8.0f));
+    }
     // lane (kq, ml): rows 16 rt + ml, channels QW kq + 4 sub + r of each strip
 #pragma unroll
     for (int ct = 0; ct < CTW; ct++) {
       if (R::SPLIT_SUB && ct >= nsub) break;           // wave-uniform
       const int j = R::SPLIT_SUB ? 0 : ct / NS;
       const int sub = R::SPLIT_SUB ? sub0 + ct : ct % NS;   // run-time only for the split strips
-      const int soff = (wq * SPW + j) * 256 + 8 * (NS * kq + sub);
+      const int soff = wq * 256 + j * (2 * SW) + 8 * (NS * kq + sub);
       const u32x2 sv = *reinterpret_cast<const u32x2*>(st + R::A_BYTES + R::W_BYTES + soff);
       u32x2 zv = u32x2{0u, 0u};
       if constexpr (HAS_ZC) zv = *reinterpret_cast<const u32x2*>(st + R::A_BYTES + R::W_BYTES + R::SC_BYTES + soff);
@@ -1942,17 +1949,21 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
         }
         const u32x4 wf = expand(w);
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) acc[rt] = mfma16<DT>(wf, bf[ks][rt], ks == 0 ? zero4 : acc[rt]);
+        for (int rt = 0; rt < RT; rt++)
+          acc[rt] = mfma16<DT>(wf, bf[ks][rt], ks == 0 ? (HAS_ZC ? zero4 : cinit[rt]) : acc[rt]);
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const float s = (r & 1) ? hi(sv[r >> 1]) : lo(sv[r >> 1]);
-        float z;
-        if constexpr (HAS_ZC) z = (r & 1) ? hi(zv[r >> 1]) : lo(zv[r >> 1]);
-        else z = DT::int4_bias + 8.0f;
+        if constexpr (HAS_ZC) {
+          const float z = (r & 1) ? hi(zv[r >> 1]) : lo(zv[r >> 1]);
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++)
-          tot[rt][ct][r] = __builtin_fmaf(s, __builtin_fmaf(-z, acc1[rt][r], acc[rt][r]), tot[rt][ct][r]);
+          for (int rt = 0; rt < RT; rt++)
+            tot[rt][ct][r] = __builtin_fmaf(s, __builtin_fmaf(-z, acc1[rt][r], acc[rt][r]), tot[rt][ct][r]);
+        } else {
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++) tot[rt][ct][r] = __builtin_fmaf(s, acc[rt][r], tot[rt][ct][r]);
+        }
       }
     }
   }
