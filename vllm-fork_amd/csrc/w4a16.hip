@@ -1771,15 +1771,18 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 1) void w4a16_mm_kernel(const Mm
 constexpr int RING_ROWS = 0;   // the two 64-row halves of a 128-row tile
 constexpr int RING_SUB = 1;    // subtiles 0-3 / 4-6 of a 112-wide strip, same 64 rows
 constexpr int RING_K = 2;      // even / odd chunks of the same 64-row tile, summed through LDS at the end
+constexpr int RING_SUBK = 3;   // 112-wide strips, few rows: two strips per workgroup; wave = (strip, even / odd chunk, subtile half)
 
 template <int NS, int SPW, bool HAS_ZC, int MODE>
 struct MmRing {
   static constexpr int CT = NS * SPW;
-  static constexpr bool SPLIT_SUB = MODE == RING_SUB, SPLIT_K = MODE == RING_K;
+  static constexpr bool SUBK = MODE == RING_SUBK;
+  static constexpr bool SPLIT_SUB = MODE == RING_SUB || SUBK, SPLIT_K = MODE == RING_K || SUBK;
   static constexpr int BM = MODE == RING_ROWS ? 128 : 64;
-  static constexpr int A_OPS = SPLIT_K ? 4 : BM / 32, W_OPS = SPLIT_K ? CT : (CT + 1) / 2, SC_OPS = HAS_ZC ? 2 : 1;
+  static constexpr int QN = SUBK ? 2 : 4;             // strip groups (of SPW strips) per workgroup
+  static constexpr int A_OPS = SPLIT_K ? 4 : BM / 32, W_OPS = MODE == RING_K ? CT : (CT + 1) / 2, SC_OPS = HAS_ZC ? 2 : 1;
   static constexpr int OPS = A_OPS + W_OPS + SC_OPS;  // LDS-DMA operations per wave and stage
-  static constexpr int A_BYTES = BM * 256, W_BYTES = 4 * CT * 1024, SC_BYTES = 4 * 256;
+  static constexpr int A_BYTES = BM * 256, W_BYTES = QN * CT * 1024, SC_BYTES = QN * 256;
   static constexpr int HALF = A_BYTES + W_BYTES + SC_BYTES * (HAS_ZC ? 2 : 1);   // one chunk's image
   static constexpr int STAGE = SPLIT_K ? 2 * HALF : HALF;                       // a stage of the K-split form holds two chunks
   static constexpr int S = (160 * 1024) / STAGE >= 4 ? 4 : (160 * 1024) / STAGE;
@@ -1803,15 +1806,18 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: LDS-DMA targets stay in SGPRs
   const int wq = wave & 3, wh = wave >> 2;
+  const int sq = R::SUBK ? (wq & 1) : wq;             // this wave's strip group
+  const int kh = R::SUBK ? (wq >> 1) : (MODE == RING_K ? wh : 0);   // this wave's chunk of a two-chunk stage
   const int kq = lane >> 4, ml = lane & 15;
-  const int strip0 = (blockIdx.x * 4 + wq) * SPW;
+  const int strip0 = (blockIdx.x * R::QN + sq) * SPW;
   const int row0 = blockIdx.y * BM;
   const int rbase = MODE == RING_ROWS ? 64 * wh : 0;  // this wave's rows inside the tile
   const int sub0 = R::SPLIT_SUB ? 4 * wh : 0;         // this wave's first subtile
   const int nsub = R::SPLIT_SUB ? (wh ? 3 : 4) : CT;
   constexpr int CSTEP = R::SPLIT_K ? 2 : 1;           // chunks per stage
-  const int cofs = R::SPLIT_K ? wh : 0;               // this wave's chunk of a stage
-  const int aw = R::SPLIT_K ? wq : wave;              // which share of the stage's rows / planes this wave fetches
+  const int cofs = kh;                                // this wave's chunk of a stage
+  // which quarter (eighth) of the chunk's activation rows this wave fetches
+  const int aw = R::SUBK ? 2 * (wq & 1) + wh : (MODE == RING_K ? wq : wave);
   const int c0 = blockIdx.z * p.cps, c1 = c0 + p.cps;
   const int groups = p.chunks / p.gchunks;
   const u32x4* wp_e = p.wp;
@@ -1845,19 +1851,19 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
     // in the K-split form every wave fetches all planes of its own chunk
 #pragma unroll
     for (int i = 0; i < R::W_OPS; i++) {
-      const int pi = R::SPLIT_K ? i : min(2 * i + wh, CT - 1), j = pi / NS, pl = pi % NS;
+      const int pi = MODE == RING_K ? i : min(2 * i + wh, CT - 1), j = pi / NS, pl = pi % NS;
       __builtin_amdgcn_global_load_lds(
           (const void __attribute__((address_space(1)))*)(wp_e + (((size_t)(strip0 + j) * p.chunks + c) * NS + pl) * 64 + lane),
-          (void __attribute__((address_space(3)))*)(st + R::A_BYTES + (wq * CT + pi) * 1024), 16, 0, 0);
+          (void __attribute__((address_space(3)))*)(st + R::A_BYTES + (sq * CT + pi) * 1024), 16, 0, 0);
     }
     const int g = c / p.gchunks;
     {   // both waves of a quad (same bytes, same place)
       const size_t off = ((size_t)(strip0 + sj) * groups + g) * SW + 2 * sdw;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(sc_e + off),
-                                       (void __attribute__((address_space(3)))*)(st + R::A_BYTES + R::W_BYTES + wq * 256), 4, 0, 0);
+                                       (void __attribute__((address_space(3)))*)(st + R::A_BYTES + R::W_BYTES + sq * 256), 4, 0, 0);
       if constexpr (HAS_ZC)
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(zc_e + off),
-                                         (void __attribute__((address_space(3)))*)(st + R::A_BYTES + R::W_BYTES + R::SC_BYTES + wq * 256), 4, 0, 0);
+                                         (void __attribute__((address_space(3)))*)(st + R::A_BYTES + R::W_BYTES + R::SC_BYTES + sq * 256), 4, 0, 0);
     }
   };
   auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
@@ -1917,7 +1923,7 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
     u32x4 wc[CT];
 #pragma unroll
     for (int i = 0; i < CT; i++)
-      wc[i] = *reinterpret_cast<const u32x4*>(st + R::A_BYTES + (wq * CT + i) * 1024 + 16 * lane);
+      wc[i] = *reinterpret_cast<const u32x4*>(st + R::A_BYTES + (sq * CT + i) * 1024 + 16 * lane);
     // symmetric weights: the products start from -(bias + 8) a1 instead of zero, which leaves one
     // multiply-add per output for the scale step (same value as s (acc - z a1) up to the order of two roundings)
     f32x4 cinit[RT];
@@ -1931,7 +1937,7 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
       if (R::SPLIT_SUB && ct >= nsub) break;           // wave-uniform
       const int j = R::SPLIT_SUB ? 0 : ct / NS;
       const int sub = R::SPLIT_SUB ? sub0 + ct : ct % NS;   // run-time only for the split strips
-      const int soff = wq * 256 + j * (2 * SW) + 8 * (NS * kq + sub);
+      const int soff = sq * 256 + j * (2 * SW) + 8 * (NS * kq + sub);
       const u32x2 sv = *reinterpret_cast<const u32x2*>(st + R::A_BYTES + R::W_BYTES + soff);
       u32x2 zv = u32x2{0u, 0u};
       if constexpr (HAS_ZC) zv = *reinterpret_cast<const u32x2*>(st + R::A_BYTES + R::W_BYTES + R::SC_BYTES + soff);
@@ -1971,19 +1977,20 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
   if constexpr (R::SPLIT_K) {   // odd-chunk sums join the even-chunk sums through the (now idle) ring
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    f32x4* red = reinterpret_cast<f32x4*>(ring) + (size_t)wq * (RT * CT) * 64 + lane;
-    if (wh) {
+    const int rslot = R::SUBK ? 2 * sq + wh : wq;     // the pair of waves that hold the same outputs
+    f32x4* red = reinterpret_cast<f32x4*>(ring) + (size_t)rslot * (RT * CTW) * 64 + lane;
+    if (kh) {
 #pragma unroll
       for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) red[(rt * CT + ct) * 64] = tot[rt][ct];
+        for (int ct = 0; ct < CTW; ct++) red[(rt * CTW + ct) * 64] = tot[rt][ct];
     }
     __syncthreads();
-    if (wh) return;
+    if (kh) return;
 #pragma unroll
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-      for (int ct = 0; ct < CT; ct++) tot[rt][ct] += red[(rt * CT + ct) * 64];
+      for (int ct = 0; ct < CTW; ct++) tot[rt][ct] += red[(rt * CTW + ct) * 64];
   }
   constexpr int QW = 4 * NS;
 #pragma unroll
@@ -2220,8 +2227,11 @@ static inline int mm_ring_form(int ns, int spw, bool grouped, int M, int cps, in
   static const int use_ring = env_int("MI355Q_MM_RING", 1);
   static const int use_ksplit = env_int("MI355Q_MM_RING_K", 1);
   static const int force_rows_min = env_int("MI355Q_MM_RING_MIN", 0);   // experiments: 128-row tiles from this many rows on
+  static const int use_subk = env_int("MI355Q_MM_RING_SUBK", 1);
   if (!use_ring || ns * spw < 4) return -1;
-  if (ns == 7) return RING_SUB;
+  // 112-wide strips, up to 128 rows: two strips per workgroup with K split inside it, so that 4096 x 28672 fills
+  // the chip without K-slices (no partial tiles, SiLU in the epilogue)
+  if (ns == 7) return (use_subk && !grouped && M <= 128 && cps % 2 == 0) ? RING_SUBK : RING_SUB;
   const bool k_ok = use_ksplit && cps % 2 == 0;
   if (grouped) return k_ok ? RING_K : -1;
   const long tiles_r = (long)colblocks * ((M + 127) / 128);
@@ -2257,7 +2267,8 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw, bool grouped = false) 
   if (N % bw) return mp;
   const int chunks = K / 128;
   const int bm = (mm_rt(M) == MM_RT && mm_ring_form(ns, spw, grouped, M, 0, N / bw) == RING_ROWS) ? 128 : 16 * mm_rt(M);
-  const long tiles = (long)(N / bw) * ((M + bm - 1) / bm);
+  const int form0 = mm_rt(M) == MM_RT ? mm_ring_form(ns, spw, grouped, M, 0, N / bw) : -1;
+  const long tiles = (long)(N / bw) * (form0 == RING_SUBK ? 2 : 1) * ((M + bm - 1) / bm);   // two strips per workgroup there
   // K-slices until about 200 workgroups exist.  The K-split ring form runs eight waves on a tile: from 120
   // workgroups on it prefers slices of 8+ chunks to more workgroups (measured at 128 rows: qkv 30.2 -> 23.8 us
   // with 4 instead of 8 slices, o 21.4 -> 20.7; down_proj, whose slices stay long, keeps its 8: 33.4 vs 43.4).
@@ -2282,7 +2293,7 @@ template <typename DT, int NS, int SPW, int MODE>
 static void launch_mm_ring_mode(const MmParams& p, int bw, hipStream_t stream) {
   using R0 = MmRing<NS, SPW, false, MODE>;
   using R1 = MmRing<NS, SPW, true, MODE>;
-  dim3 grid(p.N / bw, (p.M + R0::BM - 1) / R0::BM, p.splits), block(512);
+  dim3 grid(p.N / (R0::QN * SPW * 16 * NS), (p.M + R0::BM - 1) / R0::BM, p.splits), block(512);
   if (p.zc) hipLaunchKernelGGL((w4a16_mm_ring_kernel<DT, NS, SPW, true, MODE>), grid, block, R1::LDS, stream, p);
   else hipLaunchKernelGGL((w4a16_mm_ring_kernel<DT, NS, SPW, false, MODE>), grid, block, R0::LDS, stream, p);
 }
@@ -2291,7 +2302,8 @@ template <typename DT, int NS, int SPW>
 static void launch_mm_ring(const MmParams& p, int bw, int form, hipStream_t stream) {
   if constexpr (NS * SPW >= 4) {
     if constexpr (NS == 7) {
-      launch_mm_ring_mode<DT, NS, SPW, RING_SUB>(p, bw, stream);
+      if (form == RING_SUBK) launch_mm_ring_mode<DT, NS, SPW, RING_SUBK>(p, bw, stream);
+      else launch_mm_ring_mode<DT, NS, SPW, RING_SUB>(p, bw, stream);
     } else {
       if (form == RING_K) launch_mm_ring_mode<DT, NS, SPW, RING_K>(p, bw, stream);
       else launch_mm_ring_mode<DT, NS, SPW, RING_ROWS>(p, bw, stream);
