@@ -174,6 +174,47 @@ def test_w4a16_mm_vs_oracle(M, K, N, G, tile, awq, dt):
     assert torch.equal(out, ops.w4a16_mm(to_dev(a, dt), w, bias=to_dev(bias, dt)))
 
 
+@pytest.mark.parametrize("tile,M,awq,options", [
+    (16, 200, False, {"MI355Q_MM_RING_MIN": "129"}),       # wave halves split the rows of 128-row tiles
+    (16, 200, True, {"MI355Q_MM_RING_MIN": "129"}),
+    (16, 200, False, {"MI355Q_MM_RING_MIN": "100000"}),    # ... the chunks of 64-row tiles
+    (64, 300, True, {"MI355Q_MM_RING_MIN": "100000"}),
+    (32, 100, False, {"MI355Q_MM_RING_K": "0"}),           # no K-split form: the register-prefetch kernel
+    (16, 200, False, {"MI355Q_MM_RING": "0"}),
+    (112, 200, False, {}),                                 # 112-wide strips: subtile halves
+    (112, 100, True, {}),                                  # ... two strips per workgroup, K split inside
+    (112, 100, False, {"MI355Q_MM_RING_SUBK": "0"}),
+    (112, 100, False, {"MI355Q_MM_RING": "0"}),
+])
+def test_w4a16_mm_every_workgroup_form(tile, M, awq, options):
+    """The prompt kernel's forms (what the two wave halves of a workgroup split, or the register-prefetch
+    kernel) are chosen by shape; here each is forced on one small problem and held to the same bar."""
+    K, N, G, dt = 2048, 896 if tile == 112 else 1024, 128, orc.BF16
+    rng = np.random.default_rng(tile + M)
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    a = orc.f32_to_h16(0.25 * rng.standard_normal((M, K)).astype(np.float32), dt)
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N))).astype(np.float32), dt)
+    if awq:
+        z = rng.integers(0, 16, size=(K // G, N), dtype=np.int32)
+        qw, qz = orc.pack_cols(q, awq_order=True), orc.pack_cols(z, awq_order=True)
+        ref = orc.w4a16_gemm(a, qw, s, qz, None, G=G, dt=dt, layout=orc.W_AWQ, zp_mode=orc.ZP_AWQ)
+        w = ops.w4a16_repack(i32(qw), to_dev(s, dt), i32(qz), G, _lib.W_AWQ, _lib.ZP_AWQ, tile=tile)
+    else:
+        qw = orc.gptq_pack(q)
+        ref = orc.w4a16_gemm(a, qw, s, None, None, G=G, dt=dt)
+        w = ops.w4a16_repack(i32(qw), to_dev(s, dt), None, G, tile=tile)
+    try:
+        for k, v in options.items():
+            _lib.set_option(k, v)
+        out = ops.w4a16_mm(to_dev(a, dt), w)
+        torch.cuda.synchronize()
+    finally:
+        for k in options:
+            _lib.set_option(k, None)
+    np.testing.assert_allclose(f32(to_bits(out), dt), f32(ref, dt), rtol=1e-2, atol=1e-2)
+    assert (to_bits(out) == ref).mean() > 0.98
+
+
 @pytest.mark.parametrize("M,K,N,with_bias", [(128, 4096, 4096, False), (32, 14336, 4096, True), (600, 1024, 4096, False),
                                               (20, 512, 8192, True), (8, 14336, 4096, False), (13, 14336, 4096, True)])
 def test_w4a16_mm_add_rms_norm_equals_the_two_steps(M, K, N, with_bias):

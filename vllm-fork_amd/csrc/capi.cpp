@@ -32,7 +32,7 @@ int check_launch(const char* what) {
 namespace {
 struct Knob { const char* name; bool read; const char* value; };
 std::mutex g_env_mu;
-Knob g_knobs[32];
+Knob g_knobs[64];
 int g_nknobs = 0;
 }  // namespace
 
@@ -41,7 +41,7 @@ const char* env_value(const char* name) {
   for (int i = 0; i < g_nknobs; i++)
     if (!strcmp(g_knobs[i].name, name)) return g_knobs[i].value;
   const char* v = getenv(name);
-  if (g_nknobs < 32) g_knobs[g_nknobs++] = Knob{name, true, v ? strdup(v) : nullptr};
+  if (g_nknobs < 64) g_knobs[g_nknobs++] = Knob{name, true, v ? strdup(v) : nullptr};
   return v;
 }
 void env_override(const char* name, const char* value) {
@@ -51,7 +51,7 @@ void env_override(const char* name, const char* value) {
       g_knobs[i].value = value ? strdup(value) : nullptr;   // old strings are left alone: readers may hold them
       return;
     }
-  if (g_nknobs < 32) g_knobs[g_nknobs++] = Knob{strdup(name), true, value ? strdup(value) : nullptr};
+  if (g_nknobs < 64) g_knobs[g_nknobs++] = Knob{strdup(name), true, value ? strdup(value) : nullptr};
 }
 bool env_flag(const char* name) { return env_value(name) != nullptr; }
 int env_int(const char* name, int dflt) {

@@ -2217,17 +2217,18 @@ static inline int mm_rt(int M) {
 // of 64, so there it applies to 112-wide strips only.  Measured on the 8B layers (us, register-prefetch form
 // -> ring form): 2048 rows down 353 -> 271, o 105 -> 82, gate_up 665 -> 629, qkv 150 -> 154; 512 rows down
 // 105 -> 86; 128 rows gate_up 63.6 -> 57.6, but qkv 33.9 -> 37.7 and o 23.0 -> 24.2 on a single 128-row tile.
-// Returns the form (RING_ROWS / RING_SUB / RING_K) or -1 for the register-prefetch kernel.  cps = chunks per
+// Returns the form (RING_ROWS / RING_SUB / RING_K / RING_SUBK) or -1 for the register-prefetch kernel (the
+// knobs are looked up per call so that mi355q_set_option can switch forms inside one process).  cps = chunks per
 // K-slice when known (the K-split form takes them in pairs), else 0; colblocks = N / workgroup width.
 // Rows or K between the wave halves: a 128-row tile takes about 1.85 x the time of a K-split 64-row tile
 // (measured on the 8B layers at 2048 rows), so the choice is which grid wastes less of its last round of 256
 // workgroups -- 2048 rows: down / o 16 x 16 tiles of 128 rows = one round (255 us against 278 K-split), qkv 24 x 16
 // = 1.5 rounds (146 us against 121 K-split in three full rounds).
 static inline int mm_ring_form(int ns, int spw, bool grouped, int M, int cps, int colblocks) {
-  static const int use_ring = env_int("MI355Q_MM_RING", 1);
-  static const int use_ksplit = env_int("MI355Q_MM_RING_K", 1);
-  static const int force_rows_min = env_int("MI355Q_MM_RING_MIN", 0);   // experiments: 128-row tiles from this many rows on
-  static const int use_subk = env_int("MI355Q_MM_RING_SUBK", 1);
+  const int use_ring = env_int("MI355Q_MM_RING", 1);
+  const int use_ksplit = env_int("MI355Q_MM_RING_K", 1);
+  const int force_rows_min = env_int("MI355Q_MM_RING_MIN", 0);   // experiments: 128-row tiles from this many rows on
+  const int use_subk = env_int("MI355Q_MM_RING_SUBK", 1);
   if (!use_ring || ns * spw < 4) return -1;
   // 112-wide strips, up to 128 rows: two strips per workgroup with K split inside it, so that 4096 x 28672 fills
   // the chip without K-slices (no partial tiles, SiLU in the epilogue)
