@@ -634,6 +634,9 @@ __global__ __launch_bounds__(SW == 64 ? 512 : 1024) void w4a16_skinny_kernel(con
     __syncthreads();
     if (threadIdx.x == 0) {
       int* cnt = p.counters + (size_t)mt * gridDim.x + strip;
+      // No release fence in front of the ticket: every published word was written by an agent-scope atomic
+      // store (write-through) and waited for (vmcnt(0) + barrier above).  A fence here writes the L2 back in
+      // every workgroup: measured -28 % on decode at 32 x 1024 tokens and +36 % on TTFT(2048).
       const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = ticket == p.splits - 1;
       if (last) {
@@ -1467,6 +1470,9 @@ __global__ __launch_bounds__(512) void w4a16_rows_kernel(const RowsParams p) {
   __syncthreads();
   if (threadIdx.x == 0) {
     int* cnt = p.counters + (size_t)blockIdx.z * gridDim.x + vstrip;
+    // No release fence in front of the ticket: every published word was written by an agent-scope atomic
+    // store (write-through) and waited for (vmcnt(0) + barrier above).  A fence here writes the L2 back in
+    // every workgroup: measured -28 % on decode at 32 x 1024 tokens and +36 % on TTFT(2048).
     const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == p.splits - 1;
     if (last) {
