@@ -666,11 +666,11 @@ __global__ __launch_bounds__(HEAD) void paged_attention_reduce_kernel(const PAPa
 }
 
 // ---------------------------------------------------------------------------
-// Prompt rows over a 16-bit cache, long queries: one workgroup = 32 / gp * ... query tokens of one
-// sequence x one kv head, walking the visible context in tiles of 64 tokens with a running softmax
-// (no partitions, no scratch, no merge).  The kernel above gives every 16 MFMA columns (16 / gp query
+// Prompt rows over a 16-bit cache, long queries: one workgroup = 16 column tiles (256 / gp query tokens x gp
+// heads: 64 tokens at four query heads per kv head) of one sequence x one kv head, walking the visible context
+// in tiles of 64 tokens with a running softmax (no partitions, no scratch, no merge).  The kernel above gives every 16 MFMA columns (16 / gp query
 // tokens x gp heads) their own copy of each K/V tile; here a tile is brought into LDS once per
-// workgroup by LDS-DMA (double-buffered) and serves 8 column tiles: 4 waves x 2.
+// workgroup by LDS-DMA (double-buffered) and serves 16 column tiles: 8 waves x 2.
 //   K image [4 token tiles][DS][64 lanes x 16 B]: the piece lane (row i, k-chunk) of an MFMA A operand,
 //   exactly as the cache holds it (16 bytes = 8 head dims of one token).  Row i of token tile T is
 //   token 32 (T / 2) + 8 (i / 4) + 4 (T % 2) + i % 4 of the 64: with that order the 8 probabilities a lane
@@ -684,22 +684,27 @@ __global__ __launch_bounds__(HEAD) void paged_attention_reduce_kernel(const PAPa
 // ---------------------------------------------------------------------------
 constexpr int PF_CTL = 2;         // column tiles per wave
 constexpr int PF_KV = 64;         // context tokens per step
+constexpr int PF_NW = 8;          // waves per workgroup (two per SIMD)
 
 template <typename DT, int HEAD>
-__global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const PAParams p) {
+__global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAParams p) {
   constexpr int DS = HEAD / 32, DTILES = HEAD / 16;
   constexpr int K_BYTES = 4 * DS * 1024, V_BYTES = 2 * DTILES * 1024, STAGE = K_BYTES + V_BYTES;
   constexpr int KI = 4 * DS, VI = 2 * DTILES;     // LDS-DMA operations per stage
+  static_assert(KI % PF_NW == 0 && VI % PF_NW == 0, "pieces are shared out evenly");
   __shared__ __attribute__((aligned(1024))) unsigned char kv[2 * STAGE];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int kq = lane >> 4, col = lane & 15;
   const int g = p.num_heads / p.num_kv_heads, gp = p.gp, QB = 16 / gp;
-  const int QW = 4 * PF_CTL * QB;                  // query tokens per workgroup
-  const int seq = blockIdx.x / p.qblocks_per_seq;
+  const int QW = PF_NW * PF_CTL * QB;              // query tokens per workgroup
+  // Workgroups are numbered kv head fastest: with as many kv heads as XCDs (consecutive workgroups go to
+  // consecutive XCDs) every XCD's L2 holds the K/V of one head only.
+  const int kvh = blockIdx.x % p.num_kv_heads;
+  const int bx = blockIdx.x / p.num_kv_heads;
+  const int seq = bx / p.qblocks_per_seq;
   // a sequence's last query block (the longest context under the causal mask) is dispatched first
-  const int q0 = (p.qblocks_per_seq - 1 - (int)(blockIdx.x % p.qblocks_per_seq)) * QW;
-  const int kvh = blockIdx.y;
+  const int q0 = (p.qblocks_per_seq - 1 - bx % p.qblocks_per_seq) * QW;
   const int qstart = p.qsl[seq];
   const int qlen = p.qsl[seq + 1] - qstart;
   if (q0 >= qlen) return;
@@ -726,18 +731,22 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const PAParams p)
 #pragma unroll
     for (int ds = 0; ds < DS; ds++) qf[c][ds] = *reinterpret_cast<const u32x4*>(qp + 32 * ds + 8 * kq);
   }
-  const float slope = p.alibi ? p.alibi[kvh * g + min(hi, g - 1)] : 0.f;
+  const float c2 = p.scale * 1.44269504088896f;   // logits in the base-2 domain
+  const float slope2 = (p.alibi ? p.alibi[kvh * g + min(hi, g - 1)] : 0.f) * 1.44269504088896f;
+  // context of the wave's first query token (0: the wave has none)
+  const int wq0 = q0 + wave * PF_CTL * QB;
+  const int wave_min_ctx = wq0 < qlen ? seq_len - qlen + wq0 + 1 : 0;
 
   // LDS-DMA pieces of a stage: K pieces idx = T * DS + ds (this lane: row i = col, k-chunk kq), V pieces
   // idx = s2 * DTILES + dt (this lane: head dim 16 dt + col, tokens 8 kq .. 8 kq + 7 of group s2); a wave takes
-  // idx = wave, wave + 4, ...  Tokens past the sequence read the piece that holds its last token (valid
+  // idx = wave, wave + PF_NW, ...  Tokens past the sequence read the piece that holds its last token (valid
   // memory; their logits are masked, their V forced to zero).
   auto stage = [&](int tile, int buf) {
     unsigned char* st = kv + buf * STAGE;
     const int t0 = tile * PF_KV;
 #pragma unroll
-    for (int n = 0; n < KI / 4; n++) {
-      const int idx = wave + 4 * n, T = idx / DS, ds = idx % DS;
+    for (int n = 0; n < KI / PF_NW; n++) {
+      const int idx = wave + PF_NW * n, T = idx / DS, ds = idx % DS;
       const int tok = min(t0 + 32 * (T >> 1) + 8 * (col >> 2) + 4 * (T & 1) + (col & 3), last_tok);
       const int blk = table[tok / p.bs];
       const uint16_t* src = kc + (size_t)blk * p.kv_block_stride + ((size_t)(ds * 4 + kq) * p.bs + tok % p.bs) * 8;
@@ -745,8 +754,8 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const PAParams p)
                                        (void __attribute__((address_space(3)))*)(st + idx * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int n = 0; n < VI / 4; n++) {
-      const int idx = wave + 4 * n, s2 = idx / DTILES, dt = idx % DTILES;
+    for (int n = 0; n < VI / PF_NW; n++) {
+      const int idx = wave + PF_NW * n, s2 = idx / DTILES, dt = idx % DTILES;
       const int tok = min(t0 + 32 * s2 + 8 * kq, last_tok & ~7);
       const int blk = table[tok / p.bs];
       const uint16_t* src = vc + (size_t)blk * p.kv_block_stride + (size_t)(dt * 16 + col) * p.bs + tok % p.bs;
@@ -787,39 +796,50 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const PAParams p)
           sv[c][T] = mfma16<DT>(kf, qf[c][ds], ds == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sv[c][T]);
       }
     }
-    // ---- running softmax per column ------------------------------------------------------------
+    // ---- running softmax per column, in the base-2 domain (scale * log2 e folded into one multiply-add) -----
+    // Tiles wholly inside the context of the wave's first query token need no mask, and without ALiBi the
+    // logit, the shift by the maximum and the exponent's scaling are one fma + one v_exp per element.
     u32x4 pf[PF_CTL][2];
+    const bool plain = !p.alibi && t0 + PF_KV <= wave_min_ctx;   // wave-uniform
+    bool rescale = false;
+    float alpha[PF_CTL];
 #pragma unroll
     for (int c = 0; c < PF_CTL; c++) {
       float tmax = -INFINITY;
+      if (plain) {
 #pragma unroll
-      for (int T = 0; T < 4; T++)
+        for (int T = 0; T < 4; T++)
+          tmax = fmaxf(tmax, fmaxf(fmaxf(sv[c][T][0], sv[c][T][1]), fmaxf(sv[c][T][2], sv[c][T][3])));
+        tmax *= c2;
+      } else {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int tok = t0 + 32 * (T >> 1) + 8 * kq + 4 * (T & 1) + r;
-          float v = sv[c][T][r] * p.scale + slope * (float)(tok - ctx_c[c] + 1);
-          v = tok < ctx_c[c] ? v : -INFINITY;
-          sv[c][T][r] = v;
-          tmax = fmaxf(tmax, v);
-        }
+        for (int T = 0; T < 4; T++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int tok = t0 + 32 * (T >> 1) + 8 * kq + 4 * (T & 1) + r;
+            float v = sv[c][T][r] * c2 + slope2 * (float)(tok - ctx_c[c] + 1);
+            v = tok < ctx_c[c] ? v : -INFINITY;
+            sv[c][T][r] = v;
+            tmax = fmaxf(tmax, v);
+          }
+      }
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float mnew = fmaxf(mrun[c], tmax);
       const float mref = mnew == -INFINITY ? 0.f : mnew;
-      const float alpha = mrun[c] == -INFINITY ? 0.f : __expf(mrun[c] - mref);
+      alpha[c] = mrun[c] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mrun[c] - mref);
+      rescale |= mnew != mrun[c];
       mrun[c] = mnew;
       float ls = 0.f;
 #pragma unroll
       for (int T = 0; T < 4; T++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const float e = __expf(sv[c][T][r] - mref);
+          const float e = plain ? __builtin_amdgcn_exp2f(__builtin_fmaf(sv[c][T][r], c2, -mref)) : __builtin_amdgcn_exp2f(sv[c][T][r] - mref);
           sv[c][T][r] = e;
           ls += e;
         }
-      lrun[c] = lrun[c] * alpha + ls;
-#pragma unroll
-      for (int dt = 0; dt < DTILES; dt++) o[c][dt] *= alpha;
+      lrun[c] = lrun[c] * alpha[c] + ls;
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++) {
         pf[c][s2][0] = pack2<DT>(sv[c][2 * s2][0], sv[c][2 * s2][1]);
@@ -827,6 +847,12 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const PAParams p)
         pf[c][s2][2] = pack2<DT>(sv[c][2 * s2 + 1][0], sv[c][2 * s2 + 1][1]);
         pf[c][s2][3] = pack2<DT>(sv[c][2 * s2 + 1][2], sv[c][2 * s2 + 1][3]);
       }
+    }
+    if (__builtin_amdgcn_ballot_w64(rescale) != 0) {   // some column's maximum moved: rescale what has been summed
+#pragma unroll
+      for (int c = 0; c < PF_CTL; c++)
+#pragma unroll
+        for (int dt = 0; dt < DTILES; dt++) o[c][dt] *= alpha[c];
     }
     // ---- O^T += V^T P^T --------------------------------------------------------------------------
     const bool ragged = t0 + PF_KV > seq_len;   // the tile reaches past the sequence: unwritten cache memory
@@ -874,9 +900,9 @@ __global__ __launch_bounds__(256, 2) void prefill_flash_kernel(const PAParams p)
 template <typename DT>
 static int launch_prefill_flash(const PAParams& p_in, int head_size, int max_qlen, hipStream_t stream) {
   PAParams p = p_in;
-  const int QW = 4 * PF_CTL * (16 / p.gp);
+  const int QW = PF_NW * PF_CTL * (16 / p.gp);
   p.qblocks_per_seq = (max_qlen + QW - 1) / QW;
-  dim3 grid(p.num_seqs * p.qblocks_per_seq, p.num_kv_heads), block(256);
+  dim3 grid(p.num_seqs * p.qblocks_per_seq * p.num_kv_heads), block(64 * PF_NW);
   if (head_size == 128) hipLaunchKernelGGL((prefill_flash_kernel<DT, 128>), grid, block, 0, stream, p);
   else hipLaunchKernelGGL((prefill_flash_kernel<DT, 64>), grid, block, 0, stream, p);
   return check_launch("prefill_flash_kernel");
