@@ -754,7 +754,9 @@ def test_paged_attention_skips_prompt_rows_and_ignores_stale_cache():
     np.testing.assert_allclose(f32(to_bits(out[[0, 4]])), f32(ref), rtol=1e-5, atol=2e-3)
 
 
-@pytest.mark.parametrize("H,KVH,D,bs,fp8", [(8, 2, 128, 16, False), (4, 4, 64, 32, False), (16, 2, 128, 16, True)])
+@pytest.mark.parametrize("H,KVH,D,bs,fp8", [(8, 2, 128, 16, False), (4, 4, 64, 32, False), (16, 2, 128, 16, True),
+                                           (16, 2, 128, 16, False), (4, 2, 128, 64, False), (6, 2, 64, 16, False),
+                                           (32, 8, 128, 16, False)])
 def test_paged_prefill_attention_vs_oracle(H, KVH, D, bs, fp8):
     """Prompt rows: write K/V with reshape_and_cache, attend through the cache, compare with
     dense causal attention of the oracle (and a decode row mixed in)."""
