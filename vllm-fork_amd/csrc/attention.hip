@@ -1011,7 +1011,14 @@ extern "C" int mi355q_paged_prefill_attention(
   MI355Q_REQUIRE(query_start_loc != nullptr && max_query_len > 0, "paged_prefill_attention: query_start_loc and max_query_len are required");
   if (int e = pa_common(p, head_size, block_size, max_seq_len, dtype, kv_fp8, "paged_prefill_attention")) return e;
   // long queries over a 16-bit cache: the running-softmax kernel (K/V tiles shared by 8 column tiles through LDS)
-  if (!kv_fp8 && max_query_len >= env_int("MI355Q_PREFILL_FLASH_MIN", 32)) {
+  // ... when the query is long or the batch brings enough workgroups: a single short prompt is a handful of
+  // workgroups walking their tiles one after the other, and the partitioned kernel's many small workgroups
+  // finish sooner (us, partitioned / running: 1 x 128 tokens 12.3 / 15.1, 1 x 256 13.1 / 20.9, 1 x 512 34.1 / 33.7,
+  // 1 x 1024 91 / 59, 1 x 2048 294 / 112; 4 x 128 17.2 / 14.7, 32 x 128 96.5 / 35.8, 4 x 512 102 / 37)
+  const int flash_qw = 8 * 2 * (16 / p.gp);
+  const long flash_wgs = (long)num_seqs * ((max_query_len + flash_qw - 1) / flash_qw) * num_kv_heads;
+  if (!kv_fp8 && max_query_len >= 32 &&
+      (max_query_len >= env_int("MI355Q_PREFILL_FLASH_MIN", 512) || flash_wgs >= env_int("MI355Q_PREFILL_FLASH_WGS", 64))) {
     if (dtype == MI355Q_BF16) return launch_prefill_flash<BF16>(p, head_size, max_query_len, (hipStream_t)stream);
     return launch_prefill_flash<FP16>(p, head_size, max_query_len, (hipStream_t)stream);
   }
