@@ -3,7 +3,8 @@
   * Llama-3-8B AWQ g128, one token: the four projections exactly as LlamaRunner._layer launches them
     (add + RMSNorm prologue on qkv, plain o_proj, add + RMSNorm prologue and SiLU epilogue on gate_up,
     plain down_proj on the activated input);
-  * Llama-3-70B GPTQ g128 tensor-parallel over 8: the four per-rank shapes at 1 and 8 tokens;
+  * Llama-3-70B GPTQ g128 tensor-parallel over 8: the four per-rank shapes at 1 and 8 tokens, and as a
+    128-token prompt through the tiled prompt kernel;
   * one Mixtral-8x7B-sized expert layer (8 experts, hidden 4096, intermediate 14336, top-2, AWQ) at
     1, 2 and 8 tokens on every route of plugin/moe.py;
   * greedy tokens of a two-layer model with Llama-3-8B widths against the oracle model;
@@ -151,6 +152,23 @@ def _expert_ref(a_bits, w_u8, s_bits, z_u8, G):
     z = np.empty((2 * n2, g), dtype=np.int32)
     z[0::2], z[1::2] = z_u8 & 0xF, z_u8 >> 4
     return orc.w4a16_gemm(a_bits, qw, s, orc.pack_cols(np.ascontiguousarray(z.T)), None, G=G, zp_mode=orc.ZP_NSEQ)
+
+
+@pytest.mark.parametrize("K,N", [(8192, 1280), (1024, 8192), (8192, 7168), (3584, 8192)])
+def test_llama3_70b_tp8_rank_prompt_gemms(K, N):
+    """The per-rank projections of Llama-3-70B over 8 GPUs on a 128-token prompt: the strip width the library
+    chooses for the shape, the prompt kernel's form for it (K-slices, two-strip form, ...), against the oracle."""
+    M, G = 128, 128
+    rng = np.random.default_rng(K + N)
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    a = orc.f32_to_h16(0.25 * rng.standard_normal((M, K)).astype(np.float32))
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N))).astype(np.float32))
+    qw = orc.gptq_pack(q)
+    ref = orc.w4a16_gemm(a, qw, s, None, None, G=G)
+    w = ops.w4a16_repack(torch.from_numpy(qw).to(DEV), to_dev(s), None, G)
+    out = ops.w4a16_gemm(to_dev(a), w)   # the route a prompt of 128 tokens takes (tiled kernel where the shape allows)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=1e-2)
+    assert (to_bits(out) == ref).mean() > 0.98
 
 
 def test_mixtral_sized_expert_layer(monkeypatch):
