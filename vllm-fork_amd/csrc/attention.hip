@@ -686,11 +686,16 @@ constexpr int PF_CTL = 2;         // column tiles per wave
 constexpr int PF_KV = 64;         // context tokens per step
 constexpr int PF_NW = 8;          // waves per workgroup (two per SIMD)
 
-template <typename DT, int HEAD>
+// fp8 cache (KVFP8): a 16-byte piece holds 16 head dims of a token (K) or 16 tokens of a head dim (V), i.e. two
+// MFMA k-steps after widening.  K: step ds takes dims 16 (4 (ds / 2) + kq) + 8 (ds & 1) + j, the query fragments are
+// loaded to match.  V: a lane's piece is tokens 16 kq .. 16 kq + 15 of the tile, its halves feed the two 32-token
+// products, so row i of token tile T is token 16 (i / 4) + 8 (T / 2) + 4 (T % 2) + i % 4 there.
+template <typename DT, int HEAD, bool KVFP8>
 __global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAParams p) {
   constexpr int DS = HEAD / 32, DTILES = HEAD / 16;
-  constexpr int K_BYTES = 4 * DS * 1024, V_BYTES = 2 * DTILES * 1024, STAGE = K_BYTES + V_BYTES;
-  constexpr int KI = 4 * DS, VI = 2 * DTILES;     // LDS-DMA operations per stage
+  constexpr int KI = KVFP8 ? 4 * DS / 2 : 4 * DS, VI = KVFP8 ? DTILES : 2 * DTILES;     // LDS-DMA operations per stage
+  constexpr int K_BYTES = KI * 1024, V_BYTES = VI * 1024, STAGE = K_BYTES + V_BYTES;
+  constexpr int EB = KVFP8 ? 1 : 2;               // bytes per cache element
   static_assert(KI % PF_NW == 0 && VI % PF_NW == 0, "pieces are shared out evenly");
   __shared__ __attribute__((aligned(1024))) unsigned char kv[2 * STAGE];
   const int lane = threadIdx.x & 63;
@@ -713,8 +718,12 @@ __global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAPa
   const int wg_ctx = seq_len - qlen + q0 + q_in_wg;          // tokens visible to the workgroup's last query
   const int ntiles = (wg_ctx + PF_KV - 1) / PF_KV;
   const int32_t* table = p.block_tables + (size_t)seq * p.max_blocks;
-  const uint16_t* kc = reinterpret_cast<const uint16_t*>(p.kc) + (size_t)kvh * p.kv_head_stride;
-  const uint16_t* vc = reinterpret_cast<const uint16_t*>(p.vc) + (size_t)kvh * p.kv_head_stride;
+  const unsigned char* kc = reinterpret_cast<const unsigned char*>(p.kc) + (size_t)kvh * p.kv_head_stride * EB;
+  const unsigned char* vc = reinterpret_cast<const unsigned char*>(p.vc) + (size_t)kvh * p.kv_head_stride * EB;
+  // token of row i of token tile T / first token of a lane's V piece, relative to the tile
+  auto row_tok = [&](int T, int i) {
+    return KVFP8 ? 16 * (i >> 2) + 8 * (T >> 1) + 4 * (T & 1) + (i & 3) : 32 * (T >> 1) + 8 * (i >> 2) + 4 * (T & 1) + (i & 3);
+  };
   const int last_tok = seq_len - 1;
 
   // this lane's query columns
@@ -729,9 +738,13 @@ __global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAPa
     ctx_c[c] = col_ok[c] ? seq_len - qlen + qi + 1 : 0;
     const uint16_t* qp = p.q + (size_t)(qstart + min(qi, qlen - 1)) * p.q_stride + (size_t)(kvh * g + min(hi, g - 1)) * HEAD;
 #pragma unroll
-    for (int ds = 0; ds < DS; ds++) qf[c][ds] = *reinterpret_cast<const u32x4*>(qp + 32 * ds + 8 * kq);
+    for (int ds = 0; ds < DS; ds++) {
+      const int d0 = KVFP8 ? 16 * (4 * (ds >> 1) + kq) + 8 * (ds & 1) : 32 * ds + 8 * kq;
+      qf[c][ds] = *reinterpret_cast<const u32x4*>(qp + d0);
+    }
   }
-  const float c2 = p.scale * 1.44269504088896f;   // logits in the base-2 domain
+  const float kscale = KVFP8 ? *p.k_scale : 1.0f, vscale = KVFP8 ? *p.v_scale : 1.0f;
+  const float c2 = p.scale * kscale * 1.44269504088896f;   // logits in the base-2 domain
   const float slope2 = (p.alibi ? p.alibi[kvh * g + min(hi, g - 1)] : 0.f) * 1.44269504088896f;
   // context of the wave's first query token (0: the wave has none)
   const int wq0 = q0 + wave * PF_CTL * QB;
@@ -746,19 +759,21 @@ __global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAPa
     const int t0 = tile * PF_KV;
 #pragma unroll
     for (int n = 0; n < KI / PF_NW; n++) {
-      const int idx = wave + PF_NW * n, T = idx / DS, ds = idx % DS;
-      const int tok = min(t0 + 32 * (T >> 1) + 8 * (col >> 2) + 4 * (T & 1) + (col & 3), last_tok);
+      const int idx = wave + PF_NW * n;
+      const int T = KVFP8 ? idx / (DS / 2) : idx / DS, dc = KVFP8 ? idx % (DS / 2) : idx % DS;   // token tile, 16-byte dim piece
+      const int tok = min(t0 + row_tok(T, col), last_tok);
       const int blk = table[tok / p.bs];
-      const uint16_t* src = kc + (size_t)blk * p.kv_block_stride + ((size_t)(ds * 4 + kq) * p.bs + tok % p.bs) * 8;
+      const unsigned char* src = kc + ((size_t)blk * p.kv_block_stride) * EB + ((size_t)(dc * 4 + kq) * p.bs + tok % p.bs) * 16;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                        (void __attribute__((address_space(3)))*)(st + idx * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int n = 0; n < VI / PF_NW; n++) {
-      const int idx = wave + PF_NW * n, s2 = idx / DTILES, dt = idx % DTILES;
-      const int tok = min(t0 + 32 * s2 + 8 * kq, last_tok & ~7);
+      const int idx = wave + PF_NW * n;
+      const int s2 = KVFP8 ? 0 : idx / DTILES, dt = idx % DTILES;
+      const int tok = KVFP8 ? min(t0 + 16 * kq, last_tok & ~15) : min(t0 + 32 * s2 + 8 * kq, last_tok & ~7);
       const int blk = table[tok / p.bs];
-      const uint16_t* src = vc + (size_t)blk * p.kv_block_stride + (size_t)(dt * 16 + col) * p.bs + tok % p.bs;
+      const unsigned char* src = vc + ((size_t)blk * p.kv_block_stride + (size_t)(dt * 16 + col) * p.bs + tok % p.bs) * EB;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                        (void __attribute__((address_space(3)))*)(st + K_BYTES + idx * 1024), 16, 0, 0);
     }
@@ -788,12 +803,26 @@ __global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAPa
     f32x4 sv[PF_CTL][4];
 #pragma unroll
     for (int T = 0; T < 4; T++) {
+      if constexpr (!KVFP8) {
 #pragma unroll
-      for (int ds = 0; ds < DS; ds++) {
-        const u32x4 kf = *reinterpret_cast<const u32x4*>(st + (T * DS + ds) * 1024 + 16 * lane);
+        for (int ds = 0; ds < DS; ds++) {
+          const u32x4 kf = *reinterpret_cast<const u32x4*>(st + (T * DS + ds) * 1024 + 16 * lane);
 #pragma unroll
-        for (int c = 0; c < PF_CTL; c++)
-          sv[c][T] = mfma16<DT>(kf, qf[c][ds], ds == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sv[c][T]);
+          for (int c = 0; c < PF_CTL; c++)
+            sv[c][T] = mfma16<DT>(kf, qf[c][ds], ds == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sv[c][T]);
+        }
+      } else {
+#pragma unroll
+        for (int sp = 0; sp < DS / 2; sp++) {
+          const u32x4 raw = *reinterpret_cast<const u32x4*>(st + (T * (DS / 2) + sp) * 1024 + 16 * lane);
+          const u32x2 a0 = fp8x4_to_h16<DT>(raw[0]), a1 = fp8x4_to_h16<DT>(raw[1]);
+          const u32x2 b0 = fp8x4_to_h16<DT>(raw[2]), b1 = fp8x4_to_h16<DT>(raw[3]);
+#pragma unroll
+          for (int c = 0; c < PF_CTL; c++) {
+            sv[c][T] = mfma16<DT>(u32x4{a0[0], a0[1], a1[0], a1[1]}, qf[c][2 * sp], sp == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sv[c][T]);
+            sv[c][T] = mfma16<DT>(u32x4{b0[0], b0[1], b1[0], b1[1]}, qf[c][2 * sp + 1], sv[c][T]);
+          }
+        }
       }
     }
     // ---- running softmax per column, in the base-2 domain (scale * log2 e folded into one multiply-add) -----
@@ -816,7 +845,7 @@ __global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAPa
         for (int T = 0; T < 4; T++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const int tok = t0 + 32 * (T >> 1) + 8 * kq + 4 * (T & 1) + r;
+            const int tok = t0 + row_tok(T, 4 * kq) + r;
             float v = sv[c][T][r] * c2 + slope2 * (float)(tok - ctx_c[c] + 1);
             v = tok < ctx_c[c] ? v : -INFINITY;
             sv[c][T][r] = v;
@@ -856,23 +885,49 @@ __global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAPa
     }
     // ---- O^T += V^T P^T --------------------------------------------------------------------------
     const bool ragged = t0 + PF_KV > seq_len;   // the tile reaches past the sequence: unwritten cache memory
+    auto tail_mask = [&](int first_tok, uint32_t (&vm)[4]) {   // the lane's 8 tokens from first_tok on
+      const int nv = min(max(seq_len - first_tok, 0), 8);
 #pragma unroll
-    for (int s2 = 0; s2 < 2; s2++) {
-      uint32_t vm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      for (int e = 0; e < 4; e++) vm[e] = nv >= 2 * e + 2 ? 0xffffffffu : (nv == 2 * e + 1 ? 0x0000ffffu : 0u);
+    };
+    if constexpr (!KVFP8) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        uint32_t vm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        if (ragged) tail_mask(t0 + 32 * s2 + 8 * kq, vm);
+#pragma unroll
+        for (int dt = 0; dt < DTILES; dt++) {
+          u32x4 vf = *reinterpret_cast<const u32x4*>(st + K_BYTES + (s2 * DTILES + dt) * 1024 + 16 * lane);
+          if (ragged) {
+            // a group that starts past the sequence was fetched from the piece of the last token: all zero here
+            vf[0] &= vm[0]; vf[1] &= vm[1]; vf[2] &= vm[2]; vf[3] &= vm[3];
+          }
+#pragma unroll
+          for (int c = 0; c < PF_CTL; c++) o[c][dt] = mfma16<DT>(vf, pf[c][s2], o[c][dt]);
+        }
+      }
+    } else {
+      uint32_t vm0[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      uint32_t vm1[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
       if (ragged) {
-        const int nv = min(max(seq_len - (t0 + 32 * s2 + 8 * kq), 0), 8);
-#pragma unroll
-        for (int e = 0; e < 4; e++) vm[e] = nv >= 2 * e + 2 ? 0xffffffffu : (nv == 2 * e + 1 ? 0x0000ffffu : 0u);
+        tail_mask(t0 + 16 * kq, vm0);
+        tail_mask(t0 + 16 * kq + 8, vm1);
       }
 #pragma unroll
       for (int dt = 0; dt < DTILES; dt++) {
-        u32x4 vf = *reinterpret_cast<const u32x4*>(st + K_BYTES + (s2 * DTILES + dt) * 1024 + 16 * lane);
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(st + K_BYTES + dt * 1024 + 16 * lane);
+        const u32x2 a0 = fp8x4_to_h16<DT>(raw[0]), a1 = fp8x4_to_h16<DT>(raw[1]);
+        const u32x2 b0 = fp8x4_to_h16<DT>(raw[2]), b1 = fp8x4_to_h16<DT>(raw[3]);
+        u32x4 v0 = u32x4{a0[0], a0[1], a1[0], a1[1]}, v1 = u32x4{b0[0], b0[1], b1[0], b1[1]};
         if (ragged) {
-          // a group that starts past the sequence was fetched from the piece of the last token: all zero here
-          vf[0] &= vm[0]; vf[1] &= vm[1]; vf[2] &= vm[2]; vf[3] &= vm[3];
+          v0[0] &= vm0[0]; v0[1] &= vm0[1]; v0[2] &= vm0[2]; v0[3] &= vm0[3];
+          v1[0] &= vm1[0]; v1[1] &= vm1[1]; v1[2] &= vm1[2]; v1[3] &= vm1[3];
         }
 #pragma unroll
-        for (int c = 0; c < PF_CTL; c++) o[c][dt] = mfma16<DT>(vf, pf[c][s2], o[c][dt]);
+        for (int c = 0; c < PF_CTL; c++) {
+          o[c][dt] = mfma16<DT>(v0, pf[c][0], o[c][dt]);
+          o[c][dt] = mfma16<DT>(v1, pf[c][1], o[c][dt]);
+        }
       }
     }
   }
@@ -884,7 +939,7 @@ __global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAPa
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (!col_ok[c]) continue;
-    const float inv = 1.0f / (l + 1e-6f);
+    const float inv = vscale / (l + 1e-6f);
     const int qi = q0 + (wave * PF_CTL + c) * QB + qi_l;
     uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + ((size_t)(qstart + qi) * p.num_heads + (kvh * g + hi)) * HEAD + 4 * kq;
 #pragma unroll
@@ -898,13 +953,14 @@ __global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAPa
 }
 
 template <typename DT>
-static int launch_prefill_flash(const PAParams& p_in, int head_size, int max_qlen, hipStream_t stream) {
+static int launch_prefill_flash(const PAParams& p_in, int head_size, int kv_fp8, int max_qlen, hipStream_t stream) {
   PAParams p = p_in;
   const int QW = PF_NW * PF_CTL * (16 / p.gp);
   p.qblocks_per_seq = (max_qlen + QW - 1) / QW;
   dim3 grid(p.num_seqs * p.qblocks_per_seq * p.num_kv_heads), block(64 * PF_NW);
-  if (head_size == 128) hipLaunchKernelGGL((prefill_flash_kernel<DT, 128>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((prefill_flash_kernel<DT, 64>), grid, block, 0, stream, p);
+  if (kv_fp8) hipLaunchKernelGGL((prefill_flash_kernel<DT, 128, true>), grid, block, 0, stream, p);
+  else if (head_size == 128) hipLaunchKernelGGL((prefill_flash_kernel<DT, 128, false>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((prefill_flash_kernel<DT, 64, false>), grid, block, 0, stream, p);
   return check_launch("prefill_flash_kernel");
 }
 
@@ -1017,10 +1073,10 @@ extern "C" int mi355q_paged_prefill_attention(
   // 1 x 1024 91 / 59, 1 x 2048 294 / 112; 4 x 128 17.2 / 14.7, 32 x 128 96.5 / 35.8, 4 x 512 102 / 37)
   const int flash_qw = 8 * 2 * (16 / p.gp);
   const long flash_wgs = (long)num_seqs * ((max_query_len + flash_qw - 1) / flash_qw) * num_kv_heads;
-  if (!kv_fp8 && max_query_len >= 32 &&
+  if ((!kv_fp8 || head_size == 128) && max_query_len >= 32 &&
       (max_query_len >= env_int("MI355Q_PREFILL_FLASH_MIN", 512) || flash_wgs >= env_int("MI355Q_PREFILL_FLASH_WGS", 64))) {
-    if (dtype == MI355Q_BF16) return launch_prefill_flash<BF16>(p, head_size, max_query_len, (hipStream_t)stream);
-    return launch_prefill_flash<FP16>(p, head_size, max_query_len, (hipStream_t)stream);
+    if (dtype == MI355Q_BF16) return launch_prefill_flash<BF16>(p, head_size, kv_fp8, max_query_len, (hipStream_t)stream);
+    return launch_prefill_flash<FP16>(p, head_size, kv_fp8, max_query_len, (hipStream_t)stream);
   }
   const int QB = 16 / p.gp;
   p.qblocks_per_seq = (max_query_len + QB - 1) / QB;
