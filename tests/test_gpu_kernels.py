@@ -833,6 +833,55 @@ def test_paged_prefill_attention_vs_oracle(H, KVH, D, bs, fp8, prefill_kernel):
         assert np.abs(got - want).mean() < 4e-4
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_paged_prefill_attention_long_prompts(fp8):
+    """Llama-3-8B heads, a 1500-token prompt and a 700-token chunk behind 300 cached tokens: 24 context tiles per
+    query block, ragged last tiles, in the kernel the library picks at these lengths (running softmax).  Same bar as
+    test_paged_prefill_attention_vs_oracle."""
+    H, KVH, D, bs = 32, 8, 128, 16
+    rng = np.random.default_rng(77)
+    qlens, ctx0 = [1500, 700], [0, 300]
+    ks, vs = (0.02, 0.015) if fp8 else (1.0, 1.0)
+    tdt = torch.uint8 if fp8 else torch.bfloat16
+    x = 16 if fp8 else 8
+    seq_lens = [c + q for c, q in zip(ctx0, qlens)]
+    maxb = (max(seq_lens) + bs - 1) // bs
+    nblk = 2 * maxb + 3
+    kc = torch.zeros((nblk, KVH, D // x, bs, x), dtype=tdt, device=DEV)
+    vc = torch.zeros((nblk, KVH, D, bs), dtype=tdt, device=DEV)
+    kst = torch.tensor(ks, dtype=torch.float32, device=DEV)
+    vst = torch.tensor(vs, dtype=torch.float32, device=DEV)
+    bt = rng.permutation(nblk)[: 2 * maxb].reshape(2, maxb).astype(np.int32)
+    allq, refs = [], []
+    for s_ in range(2):
+        L = seq_lens[s_]
+        k = orc.f32_to_h16(rng.uniform(-1, 1, (L, KVH, D)).astype(np.float32))
+        v = orc.f32_to_h16(rng.uniform(-1, 1, (L, KVH, D)).astype(np.float32))
+        q = orc.f32_to_h16(rng.uniform(-1, 1, (L, H, D)).astype(np.float32))
+        slots = np.array([bt[s_, j // bs] * bs + j % bs for j in range(L)], dtype=np.int64)
+        ops.reshape_and_cache(to_dev(k), to_dev(v), kc, vc, torch.from_numpy(slots).to(DEV), "fp8" if fp8 else "auto", kst, vst)
+        if fp8:
+            k = orc.f32_to_h16(orc.e4m3_to_f32(orc.f32_to_e4m3(orc.h16_to_f32(k) / np.float32(ks))) * np.float32(ks))
+            v = orc.f32_to_h16(orc.e4m3_to_f32(orc.f32_to_e4m3(orc.h16_to_f32(v) / np.float32(vs))) * np.float32(vs))
+        refs.append(orc.prefill_attention(q, k, v, D ** -0.5)[ctx0[s_]:])
+        allq.append(q[ctx0[s_]:])
+    qd = to_dev(np.concatenate(allq, 0))
+    ref = np.concatenate(refs, 0)
+    T = qd.shape[0]
+    P = (max(seq_lens) + 255) // 256
+    out = torch.empty_like(qd)
+    tmp = torch.empty((T, H, P, D), dtype=qd.dtype, device=DEV)
+    es = torch.empty((T, H, P), dtype=torch.float32, device=DEV)
+    ml = torch.empty_like(es)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(qlens)]).astype(np.int32), device=DEV)
+    ops.paged_prefill_attention(out, es, ml, tmp, qd, kc, vc, KVH, D ** -0.5, torch.from_numpy(bt).to(DEV),
+                                torch.tensor(seq_lens, dtype=torch.int32, device=DEV), qsl, max(qlens), bs,
+                                max(seq_lens), None, "fp8" if fp8 else "auto", kst, vst)
+    got, want = f32(to_bits(out)), f32(ref)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-2 if fp8 else 4e-3)
+    assert np.abs(got - want).mean() < (1e-3 if fp8 else 4e-4)
+
+
 # ---------------------------------------------------------------------------
 # sampler inner loop
 # ---------------------------------------------------------------------------
