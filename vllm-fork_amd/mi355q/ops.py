@@ -104,9 +104,10 @@ _WS: dict = {}
 _WS_RETIRED: list = []
 DEQUANT_MATMUL_MIN_TOKENS = 32
 # token range served by the tiled matrix-core W4A16 kernel (below: the decode kernels; above: dequantise
-# once + dense GEMM, compute-bound and best left to the BLAS)
+# once + dense GEMM, compute-bound and best left to the BLAS).  Upper end by measurement on Llama-3-8B
+# (TTFT, tiled / dequantise + BLAS): 900 tokens 19.8 / 21.3 ms, 1024 19.8 / 21.1, 1280 27.5 / 24.5.
 MM_MIN_TOKENS = 17
-MM_MAX_TOKENS = int(os.environ.get("MI355Q_MM_MAX_TOKENS", "768"))
+MM_MAX_TOKENS = int(os.environ.get("MI355Q_MM_MAX_TOKENS", "1024"))
 
 
 COUNTER_BYTES = 64 * 1024   # arrival counters at the head of the workspace; partial tiles follow
