@@ -600,23 +600,44 @@ __global__ __launch_bounds__(256, (FUSED && !KVFP8) ? 1 : 3) void paged_attentio
     const int ctx_r = seq_len - qlen + q0 + cqi + 1;
     const int nparts = (ctx_r + MI355Q_PA_PARTITION - 1) / MI355Q_PA_PARTITION;
     const size_t base = (row * p.num_heads + h) * p.max_parts;
+    // Eight partitions per round trip: every load of a batch is requested before the first is used (indices past
+    // the last partition repeat it; the sums below skip them).  One partition per iteration made the merge of a
+    // 2048-token context sixteen dependent round trips -- longer than the attention itself.
+    constexpr int MB = 8;
+    auto ld32 = [](const float* q) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
     float gmax = -INFINITY;
-    for (int i = 0; i < nparts; i++)
-      gmax = fmaxf(gmax, __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p.max_logits + base + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    for (int i0 = 0; i0 < nparts; i0 += MB) {
+      float m8[MB];
+#pragma unroll
+      for (int u = 0; u < MB; u++) m8[u] = ld32(p.max_logits + base + min(i0 + u, nparts - 1));
+#pragma unroll
+      for (int u = 0; u < MB; u++) gmax = fmaxf(gmax, m8[u]);
+    }
     float wsum = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const uint16_t* tmp = reinterpret_cast<const uint16_t*>(p.tmp_out) + base * HEAD + d;
-    for (int i = 0; i < nparts; i++) {
-      const float es = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p.exp_sums + base + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      const float ml = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p.max_logits + base + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      const float w = es * __expf(ml - gmax);
-      wsum += w;
-      const u64 a = __hip_atomic_load(reinterpret_cast<const u64*>(tmp + (size_t)i * HEAD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const u64 b = __hip_atomic_load(reinterpret_cast<const u64*>(tmp + (size_t)i * HEAD) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t wd[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    for (int i0 = 0; i0 < nparts; i0 += MB) {
+      float es8[MB], ml8[MB];
+      u64 a8[MB], b8[MB];
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        acc[2 * e] += DT::to_f32((uint16_t)(wd[e] & 0xffff)) * w;
-        acc[2 * e + 1] += DT::to_f32((uint16_t)(wd[e] >> 16)) * w;
+      for (int u = 0; u < MB; u++) {
+        const int i = min(i0 + u, nparts - 1);
+        es8[u] = ld32(p.exp_sums + base + i);
+        ml8[u] = ld32(p.max_logits + base + i);
+        a8[u] = __hip_atomic_load(reinterpret_cast<const u64*>(tmp + (size_t)i * HEAD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b8[u] = __hip_atomic_load(reinterpret_cast<const u64*>(tmp + (size_t)i * HEAD) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < MB; u++) {
+        if (i0 + u < nparts) {   // in partition order, as the stand-alone merge kernel sums them
+          const float w = es8[u] * __expf(ml8[u] - gmax);
+          wsum += w;
+          const uint32_t wd[4] = {(uint32_t)a8[u], (uint32_t)(a8[u] >> 32), (uint32_t)b8[u], (uint32_t)(b8[u] >> 32)};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            acc[2 * e] += DT::to_f32((uint16_t)(wd[e] & 0xffff)) * w;
+            acc[2 * e + 1] += DT::to_f32((uint16_t)(wd[e] >> 16)) * w;
+          }
+        }
       }
     }
     const float den = wsum + 1e-6f;   // divisions, as the stand-alone merge kernel: identical results
@@ -652,14 +673,35 @@ __global__ __launch_bounds__(HEAD) void paged_attention_reduce_kernel(const PAPa
   const int nparts = (ctx + MI355Q_PA_PARTITION - 1) / MI355Q_PA_PARTITION;
   const size_t row = (size_t)(qstart + qi);
   const size_t base = (row * p.num_heads + h) * p.max_parts;
+  constexpr int MB = 8;   // partitions per round trip (indices past the last repeat it and are skipped in the sums)
   float gmax = -INFINITY;
-  for (int i = 0; i < nparts; i++) gmax = fmaxf(gmax, p.max_logits[base + i]);
+  for (int i0 = 0; i0 < nparts; i0 += MB) {
+    float m8[MB];
+#pragma unroll
+    for (int u = 0; u < MB; u++) m8[u] = p.max_logits[base + min(i0 + u, nparts - 1)];
+#pragma unroll
+    for (int u = 0; u < MB; u++) gmax = fmaxf(gmax, m8[u]);
+  }
   float wsum = 0.f, acc = 0.f;
   const uint16_t* tmp = reinterpret_cast<const uint16_t*>(p.tmp_out) + base * HEAD + threadIdx.x;
-  for (int i = 0; i < nparts; i++) {
-    const float w = p.exp_sums[base + i] * __expf(p.max_logits[base + i] - gmax);
-    wsum += w;
-    acc += DT::to_f32(tmp[(size_t)i * HEAD]) * w;
+  for (int i0 = 0; i0 < nparts; i0 += MB) {
+    float es8[MB], ml8[MB];
+    uint16_t t8[MB];
+#pragma unroll
+    for (int u = 0; u < MB; u++) {
+      const int i = min(i0 + u, nparts - 1);
+      es8[u] = p.exp_sums[base + i];
+      ml8[u] = p.max_logits[base + i];
+      t8[u] = tmp[(size_t)i * HEAD];
+    }
+#pragma unroll
+    for (int u = 0; u < MB; u++) {
+      if (i0 + u < nparts) {
+        const float w = es8[u] * __expf(ml8[u] - gmax);
+        wsum += w;
+        acc += DT::to_f32(t8[u]) * w;
+      }
+    }
   }
   reinterpret_cast<uint16_t*>(p.out)[(row * p.num_heads + h) * HEAD + threadIdx.x] =
       DT::from_f32(acc / (wsum + 1e-6f));
