@@ -182,6 +182,7 @@ def test_w4a16_mm_vs_oracle(M, K, N, G, tile, awq, dt):
     (32, 100, False, {"MI355Q_MM_RING_K": "0"}),           # no K-split form: the register-prefetch kernel
     (16, 200, False, {"MI355Q_MM_RING": "0"}),
     (112, 200, False, {}),                                 # 112-wide strips: subtile halves
+    (112, 200, False, {"MI355Q_MM_RING_ROWS7": "1", "MI355Q_MM_RING_MIN": "129"}),
     (112, 100, True, {}),                                  # ... two strips per workgroup, K split inside
     (112, 100, False, {"MI355Q_MM_RING_SUBK": "0"}),
     (112, 100, False, {"MI355Q_MM_RING": "0"}),

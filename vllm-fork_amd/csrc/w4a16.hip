@@ -1926,10 +1926,15 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
         bf[ks][rt] = *reinterpret_cast<const u32x4*>(st + (rbase + 16 * rt + ml) * 256 + 16 * ((4 * ks + kq) ^ ml));
         acc1[rt] = mfma16<DT>(ones, bf[ks][rt], ks == 0 ? zero4 : acc1[rt]);
       }
-    u32x4 wc[CT];
+    // 112-wide strips on 128-row tiles: a wave's 7 subtiles x 4 row tiles of running sums leave no room for the
+    // strip's 7 planes in registers as well; there every packed dword is read from LDS where it is used
+    constexpr bool W_FROM_LDS = NS == 7 && MODE == RING_ROWS;
+    u32x4 wc[W_FROM_LDS ? 1 : CT];
+    if constexpr (!W_FROM_LDS) {
 #pragma unroll
-    for (int i = 0; i < CT; i++)
-      wc[i] = *reinterpret_cast<const u32x4*>(st + R::A_BYTES + (sq * CT + i) * 1024 + 16 * lane);
+      for (int i = 0; i < CT; i++)
+        wc[i] = *reinterpret_cast<const u32x4*>(st + R::A_BYTES + (sq * CT + i) * 1024 + 16 * lane);
+    }
     // symmetric weights: the products start from -(bias + 8) a1 instead of zero, which leaves one
     // multiply-add per output for the scale step (same value as s (acc - z a1) up to the order of two roundings)
     f32x4 cinit[RT];
@@ -1955,6 +1960,9 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
           const int e0 = ks * NS + ct, e1 = ks * NS + 4 + ct;
           const uint32_t w0 = wc[e0 >> 2][e0 & 3], w1 = wc[min(e1, 27) >> 2][min(e1, 27) & 3];
           w = wh ? w1 : w0;
+        } else if constexpr (W_FROM_LDS) {
+          const int e = ks * NS + sub;
+          w = *reinterpret_cast<const uint32_t*>(st + R::A_BYTES + (sq * CT + (e >> 2)) * 1024 + 16 * lane + 4 * (e & 3));
         } else {
           const int e = ks * NS + sub;
           w = wc[j * NS + (e >> 2)][e & 3];
@@ -2233,12 +2241,22 @@ static inline int mm_rt(int M) {
 static inline int mm_ring_form(int ns, int spw, bool grouped, int M, int cps, int colblocks) {
   const int use_ring = env_int("MI355Q_MM_RING", 1);
   const int use_ksplit = env_int("MI355Q_MM_RING_K", 1);
-  const int force_rows_min = env_int("MI355Q_MM_RING_MIN", 0);   // experiments: 128-row tiles from this many rows on
   const int use_subk = env_int("MI355Q_MM_RING_SUBK", 1);
+  const int force_rows_min = env_int("MI355Q_MM_RING_MIN", 0);   // experiments: 128-row tiles from this many rows on
   if (!use_ring || ns * spw < 4) return -1;
   // 112-wide strips, up to 128 rows: two strips per workgroup with K split inside it, so that 4096 x 28672 fills
   // the chip without K-slices (no partial tiles, SiLU in the epilogue)
-  if (ns == 7) return (use_subk && !grouped && M <= 128 && cps % 2 == 0) ? RING_SUBK : RING_SUB;
+  if (ns == 7) {
+    if (use_subk && !grouped && M <= 128 && cps % 2 == 0) return RING_SUBK;
+    // 128-row tiles (each wave a whole strip for 64 rows: no second copy of the activation sums, balanced halves)
+    // take about 1.7 x the time of a subtile-split 64-row tile: worth it when their grid fills its rounds
+    const long tr = (long)colblocks * ((M + 127) / 128), lr = tr % 256;
+    const long rounds_s = ((long)colblocks * ((M + 63) / 64) + 255) / 256;
+    const bool rows7 = env_int("MI355Q_MM_RING_ROWS7", 1) && !grouped && M > 128 &&
+                       (force_rows_min > 0 ? M >= force_rows_min
+                                           : ((tr + 255) / 256) * 170 < rounds_s * 100 && (lr == 0 || lr >= 230));
+    return rows7 ? RING_ROWS : RING_SUB;
+  }
   const bool k_ok = use_ksplit && cps % 2 == 0;
   if (grouped) return k_ok ? RING_K : -1;
   const long tiles_r = (long)colblocks * ((M + 127) / 128);
@@ -2310,6 +2328,7 @@ static void launch_mm_ring(const MmParams& p, int bw, int form, hipStream_t stre
   if constexpr (NS * SPW >= 4) {
     if constexpr (NS == 7) {
       if (form == RING_SUBK) launch_mm_ring_mode<DT, NS, SPW, RING_SUBK>(p, bw, stream);
+      else if (form == RING_ROWS) launch_mm_ring_mode<DT, NS, SPW, RING_ROWS>(p, bw, stream);
       else launch_mm_ring_mode<DT, NS, SPW, RING_SUB>(p, bw, stream);
     } else {
       if (form == RING_K) launch_mm_ring_mode<DT, NS, SPW, RING_K>(p, bw, stream);
