@@ -196,8 +196,9 @@ int mi355q_w4a16_gemm_add_rms_norm(const void* x, int ldx, const void* residual_
                                    int split_k, mi355q_stream_t stream);
 
 /*
- * The same GEMM for many rows (prompt processing; worthwhile from 17 rows): a tiled matrix-core
- * kernel that reads the packed weight once per 64 rows instead of expanding it to 16 bits first.
+ * The same GEMM for many rows (prompt processing; worthwhile from 17 rows): tiled matrix-core
+ * kernels that read the packed weight once per 64 or 128 rows (through an LDS ring fed by LDS-DMA
+ * from 33 rows on) instead of expanding it to 16 bits first.
  * Same arithmetic as mi355q_w4a16_gemm (fp32 (q - z) * s, one rounding, bias after rounding).
  * Replaces the many-token routes of the reference: exllama reconstruct + hipBLAS
  * (q_gemm.cu:1509-1522), awq_dequantize + matmul (auto_awq.py:947-955) and the large-M tiles of
