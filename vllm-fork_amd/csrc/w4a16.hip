@@ -2166,10 +2166,13 @@ struct StreamRowsPlan {
   size_t lds;
 };
 
-// rows 17..64 (two passes above 32), strips that alone occupy the chip, K that eight waves divide
+// rows 17..32, strips that alone occupy the chip, K that eight waves divide.  The kernel itself takes up to 64
+// rows in two passes over the weights (MI355Q_STREAM_ROWS_MAX=64), but from 33 rows on the LDS-ring form of the
+// tiled kernel reads them once and wins: gate_up at 64 rows 42.0 -> 33.0 us, qkv 23.0 -> 19.5; whole decode step
+// at batch 48 4.27 -> 3.80 ms, batch 64 4.82 -> 4.29 ms.
 static StreamRowsPlan plan_stream_rows(int M, int N, int K, int G, int sw) {
   StreamRowsPlan sp{false, 0, 0, 0, 0};
-  static const int max_rows = env_int("MI355Q_STREAM_ROWS_MAX", 64);
+  const int max_rows = env_int("MI355Q_STREAM_ROWS_MAX", 32);   // looked up per call: mi355q_set_option switches it
   if (M < 17 || M > max_rows || G % 128 || K % 128 || sw % 16 || N % sw) return sp;
   const int ns = sw / 16, chunks = K / 128;
   // Every workgroup reads all M x K activations, so the activation traffic is (N / sw) x M x K x 2 bytes:
@@ -2769,7 +2772,7 @@ extern "C" int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const
   p.out = (uint16_t*)c; p.partial = nullptr;
   p.M = M; p.N = N; p.K = K; p.chunks = K / 128; p.gchunks = G / 128;
   p.epi_silu = silu_pairs ? 1 : 0;
-  // decode batches of 17..64 rows: stream every strip once
+  // decode batches of 17..32 rows: stream every strip once
   if (const StreamRowsPlan sp = plan_stream_rows(M, N, K, G, tile); sp.ok) {
     p.splits = 1; p.cps = p.chunks;
     return act_dtype == MI355Q_BF16 ? launch_stream_rows<BF16>(p, sp, (hipStream_t)stream)
