@@ -4,6 +4,7 @@ vllm/model_executor/layers/quantization/compressed_tensors/{compressed_tensors.p
 layer / scheme pairs listed in tests/quantization/test_compressed_tensors.py (W4A16 / W8A16 pack-quantized
 group and channel, fp8 W8A16, fp8 W8A8 static and dynamic) -- the checkpoints those tests download are
 not available offline, so configs of the same shape are written out here."""
+import numpy as np
 import pytest
 import torch
 
@@ -261,3 +262,80 @@ def test_mapper_renames_layer_paths_only():
     cfg.apply_vllm_mapper(Mapper())
     assert list(cfg.target_scheme_map) == ["Linear", "re:.*proj", "language_model.model.layers.0.mlp.down_proj"]
     assert cfg.ignore == ["lm_head", "language_model.model.embed.x"]
+
+
+# -- routed experts ---------------------------------------------------------------------------------------
+def _ct_expert_tensors(rng, K, N, G):
+    """One expert projection as a pack-quantized checkpoint holds it: weight_packed [N, K/8] int32 (eight
+    consecutive input channels per word, value + 8), weight_scale [N, K/G], weight_shape [N, K]."""
+    q = rng.integers(0, 16, size=(N, K), dtype=np.int64)
+    words = np.zeros((N, K // 8), dtype=np.int64)
+    for j in range(8):
+        words |= q[:, j::8] << (4 * j)
+    packed = torch.from_numpy(words.astype(np.uint32).view(np.int32))
+    scale = torch.from_numpy((0.02 * rng.random((N, K // G)) + 0.005).astype(np.float32)).to(torch.bfloat16)
+    return q, packed, scale, torch.tensor([N, K], dtype=torch.int64)
+
+
+@pytest.mark.parametrize("tp", [(0, 1), (1, 2)])
+def test_routed_experts_resolve_to_the_wna16_expert_method_and_load_transposed(tp, monkeypatch):
+    """compressed_tensors_moe.py:28-76 (scheme of expert 0's projections, "Linear" targets cover the fused
+    experts) and compressed_tensors_moe_wna16.py:136-330 (transposed parameter shapes, sharding along the
+    transposed dims)."""
+    from mi355q.plugin import FusedMoE, CompressedTensorsWNA16MoEMethod
+    from mi355q.plugin import moe as moe_mod
+    rank, size = tp
+    monkeypatch.setattr(moe_mod, "get_tensor_model_parallel_rank", lambda: rank)
+    monkeypatch.setattr(moe_mod, "get_tensor_model_parallel_world_size", lambda: size)
+    E, H, I, G = 2, 256, 128 * size, 64
+    cfg = make(w4a16_config(group_size=G))
+    moe = FusedMoE(E, 2, H, I, params_dtype=torch.bfloat16, quant_config=cfg, prefix="model.layers.0.mlp.experts")
+    assert isinstance(moe.quant_method, CompressedTensorsWNA16MoEMethod)
+    Ip = I // size
+    assert moe.w13_weight_packed.shape == (E, H // 8, 2 * Ip) and moe.w13_weight_packed.dtype == torch.int32
+    assert moe.w2_weight_packed.shape == (E, Ip // 8, H)
+    assert moe.w13_weight_scale.shape == (E, H // G, 2 * Ip) and moe.w2_weight_scale.shape == (E, Ip // G, H)
+    assert moe.w13_weight_shape.shape == (E, 2)
+    rng = np.random.default_rng(5)
+    for sid, (K, N) in (("w1", (H, I)), ("w3", (H, I)), ("w2", (I, H))):
+        q, packed, scale, shape = _ct_expert_tensors(rng, K, N, G)
+        tgt = "w2" if sid == "w2" else "w13"
+        name = f"experts.1.{sid}"
+        assert moe.weight_loader(getattr(moe, tgt + "_weight_packed"), packed, name + ".weight_packed", sid, 1, True)
+        assert moe.weight_loader(getattr(moe, tgt + "_weight_scale"), scale, name + ".weight_scale", sid, 1, True)
+        assert moe.weight_loader(getattr(moe, tgt + "_weight_shape"), shape, name + ".weight_shape", sid, 1, True)
+        assert not moe.weight_loader(getattr(moe, tgt + "_weight_packed"), torch.zeros(K, dtype=torch.int32),
+                                     name + ".weight_g_idx", sid, 1, True)
+        got_w = getattr(moe, tgt + "_weight_packed").data[1]
+        got_s = getattr(moe, tgt + "_weight_scale").data[1]
+        if sid == "w2":      # input channels sharded: rows of the transposed tensors
+            assert torch.equal(got_w, packed.t()[rank * Ip // 8:(rank + 1) * Ip // 8])
+            assert torch.equal(got_s, scale.t()[rank * Ip // G:(rank + 1) * Ip // G])
+        else:                # output channels sharded, gate before up
+            c0 = 0 if sid == "w1" else Ip
+            assert torch.equal(got_w[:, c0:c0 + Ip], packed.t()[:, rank * Ip:(rank + 1) * Ip])
+            assert torch.equal(got_s[:, c0:c0 + Ip], scale.t()[:, rank * Ip:(rank + 1) * Ip])
+        assert getattr(moe, tgt + "_weight_shape").data[1].tolist() == [N, K]
+
+
+def test_routed_expert_schemes_outside_the_kernel_are_refused():
+    """The checks of the branch without Marlin (compressed_tensors_moe_wna16.py:118-127) and of the format
+    (compressed_tensors_moe.py:76-89)."""
+    from mi355q.plugin import FusedMoE
+
+    def build(d):
+        return FusedMoE(2, 2, 256, 128, params_dtype=torch.bfloat16, quant_config=make(d), prefix="model.layers.0.mlp.experts")
+
+    with pytest.raises(ValueError, match="channelwise"):
+        build(w4a16_config(strategy="channel", group_size=None))
+    with pytest.raises(ValueError, match="actorder"):
+        build(w4a16_config(actorder="group"))
+    with pytest.raises(ValueError, match="symmetric"):
+        build(w4a16_config(symmetric=False))
+    with pytest.raises(ValueError, match="4-bit"):
+        build(w4a16_config(num_bits=8, strategy="group"))
+    d = w4a16_config()
+    d["ignore"] = ["re:.*experts.*"]
+    with pytest.raises(NotImplementedError, match="not quantized"):
+        build(d)
+    build(w4a16_config(actorder="weight"))      # reordered when quantized: nothing to do at run time

@@ -576,6 +576,56 @@ def _ct_config(fmt="pack-quantized", **weights):
     return cfg
 
 
+@pytest.mark.parametrize("T", [2, 40])
+def test_fused_moe_layer_compressed_tensors_checkpoint(T):
+    """Routed experts of a pack-quantized compressed-tensors checkpoint (compressed_tensors_moe_wna16.py:52-330):
+    transposed parameters, repack, routing and the expert GEMMs (slot route at 2 tokens, token sort + grouped
+    GEMM at 40), against the oracle restatement of the reference's torch_moe on the same values."""
+    import moe_ref
+    from mi355q.plugin import FusedMoE, CompressedTensorsWNA16MoEMethod
+    rng = np.random.default_rng(17 + T)
+    E, H, I, G, topk = 4, 512, 256, 128, 2
+    cfg = _ct_config()
+    with torch.device(DEV):
+        moe = FusedMoE(E, topk, H, I, params_dtype=torch.bfloat16, renormalize=True, quant_config=cfg,
+                       prefix="model.layers.0.mlp.experts")
+    assert isinstance(moe.quant_method, CompressedTensorsWNA16MoEMethod)
+    ck = {}
+    for e in range(E):
+        for sid, (K, N) in (("w1", (H, I)), ("w3", (H, I)), ("w2", (I, H))):
+            q = rng.integers(0, 16, size=(N, K), dtype=np.int64)                       # value + 8, output-major
+            s = orc.f32_to_h16((0.02 * rng.random((N, K // G)) + 0.005).astype(np.float32))
+            ck[e, sid] = (q, s)
+            words = np.zeros((N, K // 8), dtype=np.int64)
+            for j in range(8):
+                words |= q[:, j::8] << (4 * j)
+            tgt, name = ("w2" if sid == "w2" else "w13"), f"experts.{e}.{sid}"
+            moe.weight_loader(getattr(moe, tgt + "_weight_packed"), torch.from_numpy(words.astype(np.uint32).view(np.int32)),
+                              name + ".weight_packed", sid, e)
+            moe.weight_loader(getattr(moe, tgt + "_weight_scale"), to_dev(s).cpu(), name + ".weight_scale", sid, e)
+            moe.weight_loader(getattr(moe, tgt + "_weight_shape"), torch.tensor([N, K]), name + ".weight_shape", sid, e)
+    moe.process_weights_after_loading()
+    x = orc.f32_to_h16(rng.standard_normal((T, H)).astype(np.float32))
+    logits = orc.f32_to_h16(rng.standard_normal((T, E)).astype(np.float32))
+    got = moe(to_dev(x), to_dev(logits))
+
+    def packed(sids):   # the byte layout the oracle reads: [E, N, K/2], even k in the low nibble
+        qs, ss = [], []
+        for e in range(E):
+            q = np.concatenate([ck[e, s][0] for s in sids], axis=0)
+            qs.append((q[:, 1::2] * 16 + q[:, ::2]).astype(np.uint8))
+            ss.append(np.concatenate([ck[e, s][1] for s in sids], axis=0))
+        return np.stack(qs), np.stack(ss), None
+
+    w, ids = moe_ref.route(logits, topk, renormalize=True)
+    ref = moe_ref.moe(x, packed(("w1", "w3")), packed(("w2",)), w, ids, G)
+    # outputs reach magnitude 4-8 here, where one bf16 step is 0.03: the absolute term scales with them as in the
+    # kernel-level test of the grouped route
+    scale_mag = max(1.0, float(np.abs(f32(ref)).max()) / 4)
+    np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=5e-3 * scale_mag)
+    assert (to_bits(got) == ref).mean() > 0.9
+
+
 @pytest.mark.parametrize("sym", [True, False])
 def test_compressed_tensors_w4a16_checkpoint(sym):
     """pack-quantized INT4: weight_packed int32 [N, K/8] (8 consecutive k per word), weight_scale [N, K/G],

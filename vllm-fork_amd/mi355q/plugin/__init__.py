@@ -8,7 +8,7 @@ same semantics) are used, which is what the tests and the bundled Llama runner d
 """
 from .awq import AutoAWQConfig, AutoAWQLinearMethod
 from .compressed_tensors import (CompressedTensorsConfig, CompressedTensorsLinearMethod, CompressedTensorsW8A16Fp8,
-                                 CompressedTensorsWNA16)
+                                 CompressedTensorsWNA16, CompressedTensorsWNA16MoEMethod)
 from .fp8 import Fp8Config, Fp8LinearMethod
 from .gptq import AutoGPTQConfig, AutoGPTQLinearMethod
 from .inc import INCConfig, INCLayerConfig, INCLinearMethod, INCWna16Scheme, resolve_scheme

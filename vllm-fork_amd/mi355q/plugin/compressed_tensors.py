@@ -613,13 +613,128 @@ class CompressedTensorsConfig(QuantizationConfig):
         if isinstance(layer, Attention):
             return CompressedTensorsKVCacheMethod(self)
         if "fusedmoe" in type(layer).__name__.lower() or "routedexperts" in type(layer).__name__.lower():
-            raise NotImplementedError("compressed-tensors routed experts are not supported; GPTQ / AWQ / AutoRound "
-                                      "expert checkpoints are (MoeWNA16Method)")
+            return get_moe_method(self, layer, prefix)
         return None
+
+    def _add_fused_moe_to_target_scheme_map(self) -> None:
+        """A scheme that targets "Linear" also covers the routed experts those linears were fused into
+        (compressed_tensors.py:215-227)."""
+        if "Linear" not in self.target_scheme_map:
+            return
+        for name in ("RoutedExperts", "FusedMoE"):
+            self.target_scheme_map.setdefault(name, self.target_scheme_map["Linear"])
 
     def has_blocked_weights(self) -> bool:
         return any(s.get("weights") is not None and s["weights"].strategy == "block"
                    for s in self.target_scheme_map.values())
+
+
+def get_moe_method(quant_config: "CompressedTensorsConfig", layer: torch.nn.Module, layer_name: str):
+    """The expert method of a routed-experts layer, resolved from the scheme of expert 0's three projections,
+    which must agree (compressed_tensors_moe.py:28-76).  Weight-only 4-bit pack-quantized experts are served;
+    an ignored layer (no scheme) has no unquantized expert path here and is refused, as every other scheme is."""
+    quant_config._add_fused_moe_to_target_scheme_map()
+    dicts = [quant_config.get_scheme_dict(layer, layer_name + proj)
+             for proj in (".0.gate_proj", ".0.up_proj", ".0.down_proj")]
+    scheme = dicts.pop()
+    if not all(d == scheme for d in dicts):
+        raise ValueError("All MoE projections need to have same quantization scheme but found multiple")
+    if scheme is None:
+        raise NotImplementedError(f"compressed-tensors: routed experts '{layer_name}' are not quantized; only "
+                                  "quantized experts are served on this path")
+    weight_quant, input_quant, fmt = scheme.get("weights"), scheme.get("input_activations"), scheme.get("format")
+    if quant_config._is_wNa16_group_channel(weight_quant, input_quant):
+        if weight_quant.num_bits != 4 or fmt != PACK_QUANTIZED:
+            raise ValueError(f"For Fused MoE layers, only format {PACK_QUANTIZED} with 4-bit weights is supported, "
+                             f"got format {fmt} and {weight_quant.num_bits} bits")
+        return CompressedTensorsWNA16MoEMethod(weight_quant, input_quant, layer_name)
+    raise NotImplementedError(f"compressed-tensors: no routed-experts method for {weight_quant=}, {input_quant=}")
+
+
+class CompressedTensorsWNA16MoEMethod:
+    """Weight-only int4 routed experts of a compressed-tensors checkpoint
+    (compressed_tensors_moe/compressed_tensors_moe_wna16.py:52-130, the branch taken without Marlin: group
+    strategy, symmetric values, no activation reordering by group).  Parameters carry the reference's names and
+    its transposed shapes (:136-214, :236-330): `w13_weight_packed [E, H/8, 2I]`, `w13_weight_scale [E, H/G, 2I]`,
+    `w2_weight_packed [E, I/8, H]`, `w2_weight_scale [E, I/G, H]` (int32 words hold 8 consecutive input channels,
+    value + 8), plus the `*_weight_shape` pairs the checkpoint stores.  After loading they become the strip layout of
+    the W4A16 kernels, gate and up channels paired, and the three routes of `fused_experts` serve them."""
+
+    def __init__(self, weight_quant: "QuantizationArgs", input_quant: "QuantizationArgs | None",
+                 layer_name: str | None = None):
+        self.weight_quant, self.input_quant = weight_quant, input_quant
+        self.num_bits, self.packed_factor = weight_quant.num_bits, 32 // weight_quant.num_bits
+        self.strategy, self.group_size, self.actorder = weight_quant.strategy, weight_quant.group_size, weight_quant.actorder
+        if self.num_bits != 4:
+            raise ValueError("CompressedTensorsWNA16MoEMethod on MI355X supports int4 experts only")
+        if weight_quant.strategy != "group" or not self.group_size or self.group_size <= 0:
+            raise ValueError("channelwise is not supported by this kernel")
+        if weight_quant.actorder in ("group", "dynamic"):
+            raise ValueError("grouped actorder isn't supported by this kernel")
+        if not weight_quant.symmetric:
+            raise ValueError("Only symmetric quantization is supported for MoE")
+
+    def create_weights(self, layer, num_experts: int, hidden_size: int, intermediate_size_per_partition: int,
+                       params_dtype: torch.dtype, **extra_weight_attrs):
+        E, H, I, G, pf = num_experts, hidden_size, intermediate_size_per_partition, self.group_size, self.packed_factor
+        if H % G or I % G:
+            raise ValueError(f"group size {G} must divide the hidden size {H} and this rank's intermediate size {I}")
+        layer.group_size = G
+
+        def reg(name, t):
+            p = torch.nn.Parameter(t, requires_grad=False)
+            p.weight_loader = self._loader(layer)
+            layer.register_parameter(name, p)
+
+        reg("w13_weight_packed", torch.empty(E, H // pf, 2 * I, dtype=torch.int32))
+        reg("w2_weight_packed", torch.empty(E, I // pf, H, dtype=torch.int32))
+        reg("w13_weight_scale", torch.ones(E, H // G, 2 * I, dtype=params_dtype))
+        reg("w2_weight_scale", torch.ones(E, I // G, H, dtype=params_dtype))
+        reg("w13_weight_shape", torch.empty(E, 2, dtype=torch.int64))
+        reg("w2_weight_shape", torch.empty(E, 2, dtype=torch.int64))
+
+    @staticmethod
+    def _loader(layer):
+        def loader(param, loaded_weight: torch.Tensor, weight_name: str, shard_id: str, expert_id: int,
+                   return_success: bool = False):
+            """Checkpoint tensors are output-major (`weight_packed [N, K/8]`, `weight_scale [N, K/G]`); they are
+            transposed into the parameter and sharded along the transposed dims: gate (w1) / up (w3) over the
+            output channels, down (w2) over the input channels (fused_moe/layer.py weight_loader, `is_transposed`)."""
+            if "g_idx" in weight_name:        # static reordering was applied to the weights when they were quantized
+                return False if return_success else None
+            dst = param.data[expert_id]
+            if "weight_shape" in weight_name:
+                dst.copy_(loaded_weight.reshape(-1)[:2])
+                return True if return_success else None
+            t = loaded_weight.t()              # [K/8 or K/G, N]
+            rank, size = layer.tp_rank, layer.tp_size
+            if shard_id in ("w1", "w3"):
+                cols = dst.shape[1] // 2
+                src = t.reshape(t.shape[0], size, -1)[:, rank]
+                dst[:, :cols].copy_(src) if shard_id == "w1" else dst[:, cols:].copy_(src)
+            elif shard_id == "w2":
+                dst.copy_(t.reshape(size, -1, t.shape[1])[rank])
+            else:
+                raise ValueError(f"unknown expert shard id {shard_id}")
+            return True if return_success else None
+
+        return loader
+
+    def process_weights_after_loading(self, layer) -> None:
+        def packed(w: torch.Tensor, s: torch.Tensor, pair: bool):
+            # output-major bytes, two input channels per byte, low nibble first: the int32 words seen as bytes
+            qw = w.data.transpose(1, 2).contiguous().view(torch.uint8)
+            return ops.moe_w4a16_repack(qw, s.data.transpose(1, 2).contiguous(), None, layer.group_size, pair_halves=pair)
+
+        layer.w13_packed = packed(layer.w13_weight_packed, layer.w13_weight_scale, True)
+        layer.w2_packed = packed(layer.w2_weight_packed, layer.w2_weight_scale, False)
+        for name in ("w13_weight_packed", "w2_weight_packed", "w13_weight_scale", "w2_weight_scale",
+                     "w13_weight_shape", "w2_weight_shape"):
+            del layer._parameters[name]
+
+    def apply(self, layer, x: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
+        from .moe import fused_experts
+        return fused_experts(x, layer.w13_packed, layer.w2_packed, topk_weights, topk_ids, layer.expert_map)
 
 
 class CompressedTensorsLinearMethod(LinearMethodBase):
