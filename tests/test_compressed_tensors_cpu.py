@@ -330,8 +330,8 @@ def test_routed_expert_schemes_outside_the_kernel_are_refused():
         build(w4a16_config(strategy="channel", group_size=None))
     with pytest.raises(ValueError, match="actorder"):
         build(w4a16_config(actorder="group"))
-    with pytest.raises(ValueError, match="symmetric"):
-        build(w4a16_config(symmetric=False))
+    asym = build(w4a16_config(symmetric=False))     # zero points: eight output channels per word
+    assert asym.w13_weight_zero_point.shape == (2, 2, 2 * 128 // 8) and asym.w2_weight_zero_point.shape == (2, 1, 256 // 8)
     with pytest.raises(ValueError, match="4-bit"):
         build(w4a16_config(num_bits=8, strategy="group"))
     d = w4a16_config()

@@ -576,46 +576,56 @@ def _ct_config(fmt="pack-quantized", **weights):
     return cfg
 
 
-@pytest.mark.parametrize("T", [2, 40])
-def test_fused_moe_layer_compressed_tensors_checkpoint(T):
+@pytest.mark.parametrize("T,sym", [(2, True), (40, True), (3, False), (40, False)])
+def test_fused_moe_layer_compressed_tensors_checkpoint(T, sym):
     """Routed experts of a pack-quantized compressed-tensors checkpoint (compressed_tensors_moe_wna16.py:52-330):
-    transposed parameters, repack, routing and the expert GEMMs (slot route at 2 tokens, token sort + grouped
-    GEMM at 40), against the oracle restatement of the reference's torch_moe on the same values."""
+    transposed parameters, repack, routing and the expert GEMMs (slot route at 2-3 tokens, token sort + grouped
+    GEMM at 40), symmetric and with zero points, against the oracle restatement of the reference's torch_moe
+    on the same values."""
     import moe_ref
     from mi355q.plugin import FusedMoE, CompressedTensorsWNA16MoEMethod
     rng = np.random.default_rng(17 + T)
     E, H, I, G, topk = 4, 512, 256, 128, 2
-    cfg = _ct_config()
+    cfg = _ct_config(symmetric=sym)
     with torch.device(DEV):
         moe = FusedMoE(E, topk, H, I, params_dtype=torch.bfloat16, renormalize=True, quant_config=cfg,
                        prefix="model.layers.0.mlp.experts")
     assert isinstance(moe.quant_method, CompressedTensorsWNA16MoEMethod)
+
+    def words(v):   # eight consecutive entries of the last dim per int32, least significant nibble first
+        out = np.zeros(v.shape[:-1] + (v.shape[-1] // 8,), dtype=np.int64)
+        for j in range(8):
+            out |= v[..., j::8] << (4 * j)
+        return torch.from_numpy(out.astype(np.uint32).view(np.int32))
+
     ck = {}
     for e in range(E):
         for sid, (K, N) in (("w1", (H, I)), ("w3", (H, I)), ("w2", (I, H))):
-            q = rng.integers(0, 16, size=(N, K), dtype=np.int64)                       # value + 8, output-major
+            q = rng.integers(0, 16, size=(N, K), dtype=np.int64)                       # stored nibble, output-major
+            z = rng.integers(0, 16, size=(N, K // G), dtype=np.int64)
             s = orc.f32_to_h16((0.02 * rng.random((N, K // G)) + 0.005).astype(np.float32))
-            ck[e, sid] = (q, s)
-            words = np.zeros((N, K // 8), dtype=np.int64)
-            for j in range(8):
-                words |= q[:, j::8] << (4 * j)
+            ck[e, sid] = (q, s, z)
             tgt, name = ("w2" if sid == "w2" else "w13"), f"experts.{e}.{sid}"
-            moe.weight_loader(getattr(moe, tgt + "_weight_packed"), torch.from_numpy(words.astype(np.uint32).view(np.int32)),
-                              name + ".weight_packed", sid, e)
+            moe.weight_loader(getattr(moe, tgt + "_weight_packed"), words(q), name + ".weight_packed", sid, e)
             moe.weight_loader(getattr(moe, tgt + "_weight_scale"), to_dev(s).cpu(), name + ".weight_scale", sid, e)
             moe.weight_loader(getattr(moe, tgt + "_weight_shape"), torch.tensor([N, K]), name + ".weight_shape", sid, e)
+            if not sym:   # [N/8, K/G]: packed along the output channels
+                moe.weight_loader(getattr(moe, tgt + "_weight_zero_point"), words(np.ascontiguousarray(z.T)).t().contiguous(),
+                                  name + ".weight_zero_point", sid, e)
     moe.process_weights_after_loading()
     x = orc.f32_to_h16(rng.standard_normal((T, H)).astype(np.float32))
     logits = orc.f32_to_h16(rng.standard_normal((T, E)).astype(np.float32))
     got = moe(to_dev(x), to_dev(logits))
 
-    def packed(sids):   # the byte layout the oracle reads: [E, N, K/2], even k in the low nibble
-        qs, ss = [], []
+    def packed(sids):   # the byte layouts the oracle reads: [E, N, K/2] even k low, zeros [E, N/2, K/G] even n low
+        qs, ss, zs = [], [], []
         for e in range(E):
             q = np.concatenate([ck[e, s][0] for s in sids], axis=0)
+            z = np.concatenate([ck[e, s][2] for s in sids], axis=0)
             qs.append((q[:, 1::2] * 16 + q[:, ::2]).astype(np.uint8))
+            zs.append((z[1::2] * 16 + z[::2]).astype(np.uint8))
             ss.append(np.concatenate([ck[e, s][1] for s in sids], axis=0))
-        return np.stack(qs), np.stack(ss), None
+        return np.stack(qs), np.stack(ss), (None if sym else np.stack(zs))
 
     w, ids = moe_ref.route(logits, topk, renormalize=True)
     ref = moe_ref.moe(x, packed(("w1", "w3")), packed(("w2",)), w, ids, G)

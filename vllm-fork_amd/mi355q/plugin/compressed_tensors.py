@@ -653,11 +653,12 @@ def get_moe_method(quant_config: "CompressedTensorsConfig", layer: torch.nn.Modu
 
 class CompressedTensorsWNA16MoEMethod:
     """Weight-only int4 routed experts of a compressed-tensors checkpoint
-    (compressed_tensors_moe/compressed_tensors_moe_wna16.py:52-130, the branch taken without Marlin: group
-    strategy, symmetric values, no activation reordering by group).  Parameters carry the reference's names and
+    (compressed_tensors_moe/compressed_tensors_moe_wna16.py:52-130, the checks of the branch taken without
+    Marlin -- group strategy, no activation reordering by group -- and zero points as the Marlin branch holds them).  Parameters carry the reference's names and
     its transposed shapes (:136-214, :236-330): `w13_weight_packed [E, H/8, 2I]`, `w13_weight_scale [E, H/G, 2I]`,
     `w2_weight_packed [E, I/8, H]`, `w2_weight_scale [E, I/G, H]` (int32 words hold 8 consecutive input channels,
-    value + 8), plus the `*_weight_shape` pairs the checkpoint stores.  After loading they become the strip layout of
+    value + 8 for symmetric checkpoints; asymmetric ones add `w13_weight_zero_point [E, H/G, 2I/8]`,
+    `w2_weight_zero_point [E, I/G, H/8]`), plus the `*_weight_shape` pairs the checkpoint stores.  After loading they become the strip layout of
     the W4A16 kernels, gate and up channels paired, and the three routes of `fused_experts` serve them."""
 
     def __init__(self, weight_quant: "QuantizationArgs", input_quant: "QuantizationArgs | None",
@@ -671,8 +672,7 @@ class CompressedTensorsWNA16MoEMethod:
             raise ValueError("channelwise is not supported by this kernel")
         if weight_quant.actorder in ("group", "dynamic"):
             raise ValueError("grouped actorder isn't supported by this kernel")
-        if not weight_quant.symmetric:
-            raise ValueError("Only symmetric quantization is supported for MoE")
+        self.symmetric = weight_quant.symmetric   # zero points as the reference's Marlin branch takes them (:357-387)
 
     def create_weights(self, layer, num_experts: int, hidden_size: int, intermediate_size_per_partition: int,
                        params_dtype: torch.dtype, **extra_weight_attrs):
@@ -692,12 +692,16 @@ class CompressedTensorsWNA16MoEMethod:
         reg("w2_weight_scale", torch.ones(E, I // G, H, dtype=params_dtype))
         reg("w13_weight_shape", torch.empty(E, 2, dtype=torch.int64))
         reg("w2_weight_shape", torch.empty(E, 2, dtype=torch.int64))
+        if not self.symmetric:                # eight consecutive output channels per word
+            reg("w13_weight_zero_point", torch.zeros(E, H // G, 2 * I // pf, dtype=torch.int32))
+            reg("w2_weight_zero_point", torch.zeros(E, I // G, H // pf, dtype=torch.int32))
 
     @staticmethod
     def _loader(layer):
         def loader(param, loaded_weight: torch.Tensor, weight_name: str, shard_id: str, expert_id: int,
                    return_success: bool = False):
-            """Checkpoint tensors are output-major (`weight_packed [N, K/8]`, `weight_scale [N, K/G]`); they are
+            """Checkpoint tensors are output-major (`weight_packed [N, K/8]`, `weight_scale [N, K/G]`,
+            `weight_zero_point [N/8, K/G]`); they are
             transposed into the parameter and sharded along the transposed dims: gate (w1) / up (w3) over the
             output channels, down (w2) over the input channels (fused_moe/layer.py weight_loader, `is_transposed`)."""
             if "g_idx" in weight_name:        # static reordering was applied to the weights when they were quantized
@@ -721,16 +725,20 @@ class CompressedTensorsWNA16MoEMethod:
         return loader
 
     def process_weights_after_loading(self, layer) -> None:
-        def packed(w: torch.Tensor, s: torch.Tensor, pair: bool):
+        def packed(w: torch.Tensor, s: torch.Tensor, z: "torch.Tensor | None", pair: bool):
             # output-major bytes, two input channels per byte, low nibble first: the int32 words seen as bytes
             qw = w.data.transpose(1, 2).contiguous().view(torch.uint8)
-            return ops.moe_w4a16_repack(qw, s.data.transpose(1, 2).contiguous(), None, layer.group_size, pair_halves=pair)
+            # zero points: the words seen as bytes hold two output channels each, [E, K/G, N/2] -> [E, N/2, K/G]
+            qz = None if z is None else z.data.contiguous().view(torch.uint8).transpose(1, 2).contiguous()
+            return ops.moe_w4a16_repack(qw, s.data.transpose(1, 2).contiguous(), qz, layer.group_size, pair_halves=pair)
 
-        layer.w13_packed = packed(layer.w13_weight_packed, layer.w13_weight_scale, True)
-        layer.w2_packed = packed(layer.w2_weight_packed, layer.w2_weight_scale, False)
+        z13 = None if self.symmetric else layer.w13_weight_zero_point
+        z2 = None if self.symmetric else layer.w2_weight_zero_point
+        layer.w13_packed = packed(layer.w13_weight_packed, layer.w13_weight_scale, z13, True)
+        layer.w2_packed = packed(layer.w2_weight_packed, layer.w2_weight_scale, z2, False)
         for name in ("w13_weight_packed", "w2_weight_packed", "w13_weight_scale", "w2_weight_scale",
-                     "w13_weight_shape", "w2_weight_shape"):
-            del layer._parameters[name]
+                     "w13_weight_shape", "w2_weight_shape", "w13_weight_zero_point", "w2_weight_zero_point"):
+            layer._parameters.pop(name, None)
 
     def apply(self, layer, x: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
         from .moe import fused_experts
