@@ -371,6 +371,14 @@ def test_w4a16_many_token_route_vs_oracle(monkeypatch):
     w = ops.w4a16_repack(i32(qw), to_dev(s), None, G)
     out = ops.w4a16_gemm(to_dev(a), w, bias=to_dev(bias))
     np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-2, atol=1e-2)
+    # the opt-in resident expanded copy: expanded at first use, kept, same product
+    assert w.dense is None
+    monkeypatch.setattr(ops, "DENSE_RESIDENT", True)
+    first = ops.w4a16_gemm(to_dev(a), w, bias=to_dev(bias))
+    kept = w.dense
+    assert kept is not None and kept.shape == (K, N)
+    again = ops.w4a16_gemm(to_dev(a), w, bias=to_dev(bias))
+    assert w.dense is kept and torch.equal(first, out) and torch.equal(again, out)
 
 
 def test_w4a16_split_k_invariance_of_argmax():

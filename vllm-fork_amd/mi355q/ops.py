@@ -43,11 +43,12 @@ def _need_cuda(*ts):
 class PackedW4:
     """Kernel-layout 4-bit weight of one linear layer (output of `w4a16_repack`)."""
 
-    __slots__ = ("packed", "scales", "zc", "K", "N", "G", "tile", "pair_halves")
+    __slots__ = ("packed", "scales", "zc", "K", "N", "G", "tile", "pair_halves", "dense")
 
     def __init__(self, packed, scales, zc, K, N, G, tile, pair_halves=False):
         self.packed, self.scales, self.zc, self.K, self.N, self.G, self.tile = packed, scales, zc, K, N, G, tile
         self.pair_halves = pair_halves
+        self.dense = None   # expanded [K, N] copy, kept only under MI355Q_PROMPT_DENSE_RESIDENT=1
 
 
 def w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor | None,
@@ -108,6 +109,11 @@ DEQUANT_MATMUL_MIN_TOKENS = 32
 # (TTFT, tiled / dequantise + BLAS): 900 tokens 19.8 / 21.3 ms, 1024 19.8 / 21.1, 1280 27.5 / 24.5.
 MM_MIN_TOKENS = 17
 MM_MAX_TOKENS = int(os.environ.get("MI355Q_MM_MAX_TOKENS", "1024"))
+# Above MM_MAX_TOKENS every call expands the layer's weights into the staging buffer first (a quarter of the
+# route's time at 2048 tokens).  With 288 GB per GPU a deployment may prefer to keep the expanded copy of
+# every layer next to the packed one (4 x the packed bytes: 14 GB for Llama-3-8B): decode still streams the
+# 4-bit weights, long prompts skip the expansion.  Off by default -- the packed weight stays the only copy.
+DENSE_RESIDENT = os.environ.get("MI355Q_PROMPT_DENSE_RESIDENT", "0") == "1"
 
 
 COUNTER_BYTES = 64 * 1024   # arrival counters at the head of the workspace; partial tiles follow
@@ -155,7 +161,13 @@ def w4a16_gemm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, s
             act = torch.empty((M, w.K), dtype=x.dtype, device=x.device)
             silu_and_mul(act, x2.contiguous())
             x2 = act
-        res = torch.matmul(x2, w4a16_dequantize(w, out=_dequant_stage(w)), out=out)
+        if DENSE_RESIDENT:
+            if w.dense is None:
+                w.dense = w4a16_dequantize(w)
+            dense = w.dense
+        else:
+            dense = w4a16_dequantize(w, out=_dequant_stage(w))
+        res = torch.matmul(x2, dense, out=out)
         if bias is not None:
             res.add_(bias)
         return res.reshape(x.shape[:-1] + (w.N,))
