@@ -19,7 +19,7 @@ def run(cases, seed, verbose=True):
         N = bw * int(rng.integers(1, 5))
         K = 128 * int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 28]))
         G = int(rng.choice([128, K])) if K % 128 == 0 else 128
-        M = int(rng.choice([17, 31, 33, 64, 65, 100, 128, 129, 200, 256, 300, 511, 640]))
+        M = int(rng.choice([17, 31, 33, 40, 48, 64, 65, 100, 128, 129, 200, 256, 300, 511, 640]))
         awq = bool(rng.integers(0, 2))
         dt = orc.BF16 if rng.integers(0, 3) else orc.FP16
         tdt = torch.bfloat16 if dt == orc.BF16 else torch.float16
