@@ -765,16 +765,20 @@ def test_paged_attention_skips_prompt_rows_and_ignores_stale_cache():
 
 @pytest.fixture
 def prefill_kernel(request):
-    """Forces the partitioned or the running-softmax prompt kernel (the library picks by query length and batch)."""
+    """Forces the partitioned or the running-softmax prompt kernel, the latter in its 64- ("running") or 32-token
+    ("running32") form (the library picks by query length and batch)."""
     v = "100000000" if request.param == "partitioned" else "32"
     _lib.set_option("MI355Q_PREFILL_FLASH_MIN", v)
     _lib.set_option("MI355Q_PREFILL_FLASH_WGS", v)
-    yield request.param
+    if request.param != "partitioned":
+        _lib.set_option("MI355Q_PREFILL_FLASH_CTL", "1" if request.param == "running32" else "2")
+    yield "running" if request.param == "running32" else request.param
     _lib.set_option("MI355Q_PREFILL_FLASH_MIN", None)
     _lib.set_option("MI355Q_PREFILL_FLASH_WGS", None)
+    _lib.set_option("MI355Q_PREFILL_FLASH_CTL", None)
 
 
-@pytest.mark.parametrize("prefill_kernel", ["partitioned", "running"], indirect=True)
+@pytest.mark.parametrize("prefill_kernel", ["partitioned", "running", "running32"], indirect=True)
 @pytest.mark.parametrize("H,KVH,D,bs,fp8", [(8, 2, 128, 16, False), (4, 4, 64, 32, False), (16, 2, 128, 16, True),
                                            (16, 2, 128, 16, False), (4, 2, 128, 64, False), (6, 2, 64, 16, False),
                                            (32, 8, 128, 16, False)])
@@ -842,11 +846,20 @@ def test_paged_prefill_attention_vs_oracle(H, KVH, D, bs, fp8, prefill_kernel):
         assert np.abs(got - want).mean() < 4e-4
 
 
+@pytest.mark.parametrize("narrow", [False, True])
 @pytest.mark.parametrize("fp8", [False, True])
-def test_paged_prefill_attention_long_prompts(fp8):
+def test_paged_prefill_attention_long_prompts(fp8, narrow):
     """Llama-3-8B heads, a 1500-token prompt and a 700-token chunk behind 300 cached tokens: 24 context tiles per
-    query block, ragged last tiles, in the kernel the library picks at these lengths (running softmax).  Same bar as
-    test_paged_prefill_attention_vs_oracle."""
+    query block, ragged last tiles, in the kernel the library picks at these lengths (running softmax, 64 query
+    tokens per workgroup) and in its 32-token form.  Same bar as test_paged_prefill_attention_vs_oracle."""
+    _lib.set_option("MI355Q_PREFILL_FLASH_CTL", "1" if narrow else None)
+    try:
+        _long_prompts_case(fp8)
+    finally:
+        _lib.set_option("MI355Q_PREFILL_FLASH_CTL", None)
+
+
+def _long_prompts_case(fp8):
     H, KVH, D, bs = 32, 8, 128, 16
     rng = np.random.default_rng(77)
     qlens, ctx0 = [1500, 700], [0, 300]

@@ -32,3 +32,4 @@ def test_prompt_attention_random_configurations(seed):
     finally:
         _lib.set_option("MI355Q_PREFILL_FLASH_MIN", None)
         _lib.set_option("MI355Q_PREFILL_FLASH_WGS", None)
+        _lib.set_option("MI355Q_PREFILL_FLASH_CTL", None)

@@ -46,9 +46,10 @@ def run(cases, seed, verbose=True):
         T = qd.shape[0]; P = (max(seq_lens) + 255) // 256
         qsl = torch.tensor(np.concatenate([[0], np.cumsum(qlens)]).astype(np.int32), device=DEV)
         line = f"case {it}: H {H:2d} KVH {KVH} D {D:3d} bs {bs:2d} fp8 {int(fp8)} q {qlens} ctx0 {ctx0}:"
-        for name, v_ in (("partitioned", "100000000"), ("running", "32")):
-            if name == "running" and fp8 and D != 128: continue
+        for name, v_, ctl in (("partitioned", "100000000", None), ("running", "32", "2"), ("running32", "32", "1")):
+            if name != "partitioned" and fp8 and D != 128: continue
             _lib.set_option("MI355Q_PREFILL_FLASH_MIN", v_); _lib.set_option("MI355Q_PREFILL_FLASH_WGS", v_)
+            _lib.set_option("MI355Q_PREFILL_FLASH_CTL", ctl)
             out = torch.full_like(qd, 7.0)
             tmp = torch.empty((T, H, P, D), dtype=qd.dtype, device=DEV); es = torch.empty((T, H, P), dtype=torch.float32, device=DEV); ml = torch.empty_like(es)
             ops.paged_prefill_attention(out, es, ml, tmp, qd, kc, vc, KVH, D ** -0.5, torch.from_numpy(bt).to(DEV),

@@ -724,7 +724,6 @@ __global__ __launch_bounds__(HEAD) void paged_attention_reduce_kernel(const PAPa
 // (the reference's own prompt kernel is held to atol 1e-4 on values of magnitude 1e-3,
 // tests/kernels/attention/test_prefix_prefill.py:159-163,322-323).
 // ---------------------------------------------------------------------------
-constexpr int PF_CTL = 2;         // column tiles per wave
 constexpr int PF_KV = 64;         // context tokens per step
 constexpr int PF_NW = 8;          // waves per workgroup (two per SIMD)
 
@@ -732,8 +731,10 @@ constexpr int PF_NW = 8;          // waves per workgroup (two per SIMD)
 // MFMA k-steps after widening.  K: step ds takes dims 16 (4 (ds / 2) + kq) + 8 (ds & 1) + j, the query fragments are
 // loaded to match.  V: a lane's piece is tokens 16 kq .. 16 kq + 15 of the tile, its halves feed the two 32-token
 // products, so row i of token tile T is token 16 (i / 4) + 8 (T / 2) + 4 (T % 2) + i % 4 there.
-template <typename DT, int HEAD, bool KVFP8>
-__global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAParams p) {
+// PF_CTL = column tiles per wave: 2 (64 query tokens x 4 heads per workgroup, one workgroup per CU) or 1 (32 tokens,
+// two workgroups per CU).
+template <typename DT, int HEAD, bool KVFP8, int PF_CTL>
+__global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 2 : 1) void prefill_flash_kernel(const PAParams p) {
   constexpr int DS = HEAD / 32, DTILES = HEAD / 16;
   constexpr int KI = KVFP8 ? 4 * DS / 2 : 4 * DS, VI = KVFP8 ? DTILES : 2 * DTILES;     // LDS-DMA operations per stage
   constexpr int K_BYTES = KI * 1024, V_BYTES = VI * 1024, STAGE = K_BYTES + V_BYTES;
@@ -994,16 +995,34 @@ __global__ __launch_bounds__(64 * PF_NW, 1) void prefill_flash_kernel(const PAPa
   }
 }
 
-template <typename DT>
-static int launch_prefill_flash(const PAParams& p_in, int head_size, int kv_fp8, int max_qlen, hipStream_t stream) {
+template <typename DT, int CTL>
+static int launch_prefill_flash_ctl(const PAParams& p_in, int head_size, int kv_fp8, int max_qlen, hipStream_t stream) {
   PAParams p = p_in;
-  const int QW = PF_NW * PF_CTL * (16 / p.gp);
+  const int QW = PF_NW * CTL * (16 / p.gp);
   p.qblocks_per_seq = (max_qlen + QW - 1) / QW;
   dim3 grid(p.num_seqs * p.qblocks_per_seq * p.num_kv_heads), block(64 * PF_NW);
-  if (kv_fp8) hipLaunchKernelGGL((prefill_flash_kernel<DT, 128, true>), grid, block, 0, stream, p);
-  else if (head_size == 128) hipLaunchKernelGGL((prefill_flash_kernel<DT, 128, false>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((prefill_flash_kernel<DT, 64, false>), grid, block, 0, stream, p);
+  if (kv_fp8) hipLaunchKernelGGL((prefill_flash_kernel<DT, 128, true, CTL>), grid, block, 0, stream, p);
+  else if (head_size == 128) hipLaunchKernelGGL((prefill_flash_kernel<DT, 128, false, CTL>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((prefill_flash_kernel<DT, 64, false, CTL>), grid, block, 0, stream, p);
   return check_launch("prefill_flash_kernel");
+}
+
+// 32 or 64 query tokens per workgroup.  The narrow form reads every K/V tile twice as often but brings twice the
+// workgroups, two resident per CU, and halves the longest one under the causal mask.  Measured (32 query / 8 kv heads
+// of 128; us, 64-token form -> 32-token form): 1 x 512 tokens 33.5 -> 24.8, 1 x 1024 58.5 -> 44.1, 1 x 2048 112 -> 91,
+// 1 x 3072 166 -> 157, 1 x 4096 237 -> 259; 8 x 128 16.3 -> 12.9, 32 x 128 35.9 -> 29.3, 64 x 128 67.9 -> 56.1,
+// 32 x 256 88.7 -> 74.2, 8 x 512 68.9 -> 59.7, 16 x 512 120 -> 106; but 4 x 512 35.6 -> 38.1, 2 x 1024 60.8 -> 67.4,
+// 2 x 2048 136 -> 152, 32 x 1024 662 -> 662.  Taken where the wide form leaves CUs idle, for short prompts in
+// batches beyond one round, and for a single prompt up to about 3000 tokens (MI355Q_PREFILL_FLASH_CTL = 1 / 2 forces).
+template <typename DT>
+static int launch_prefill_flash(const PAParams& p_in, int head_size, int kv_fp8, int max_qlen, hipStream_t stream) {
+  const int qw2 = PF_NW * 2 * (16 / p_in.gp);
+  const long wgs2 = (long)p_in.num_seqs * ((max_qlen + qw2 - 1) / qw2) * p_in.num_kv_heads;
+  const int forced = env_int("MI355Q_PREFILL_FLASH_CTL", 0);
+  const bool narrow = forced ? forced == 1
+                             : (wgs2 < 256 || (max_qlen <= 512 && wgs2 > 256) || (p_in.num_seqs == 1 && wgs2 <= 384));
+  if (narrow) return launch_prefill_flash_ctl<DT, 1>(p_in, head_size, kv_fp8, max_qlen, stream);
+  return launch_prefill_flash_ctl<DT, 2>(p_in, head_size, kv_fp8, max_qlen, stream);
 }
 
 template <typename DT>
@@ -1111,12 +1130,13 @@ extern "C" int mi355q_paged_prefill_attention(
   // long queries over a 16-bit cache: the running-softmax kernel (K/V tiles shared by 8 column tiles through LDS)
   // ... when the query is long or the batch brings enough workgroups: a single short prompt is a handful of
   // workgroups walking their tiles one after the other, and the partitioned kernel's many small workgroups
-  // finish sooner (us, partitioned / running: 1 x 128 tokens 12.3 / 15.1, 1 x 256 13.1 / 20.9, 1 x 512 34.1 / 33.7,
-  // 1 x 1024 91 / 59, 1 x 2048 294 / 112; 4 x 128 17.2 / 14.7, 32 x 128 96.5 / 35.8, 4 x 512 102 / 37)
+  // finish sooner (us, partitioned / running in the form launch_prefill_flash picks: 1 x 128 tokens 14.9 / 14.9,
+  // 1 x 256 14.6 / 15.0, 1 x 384 25.8 / 19.6, 1 x 512 37.1 / 24.6, 1 x 1024 94 / 44, 1 x 2048 295 / 93;
+  // 2 x 128 12.2 / 11.5, 2 x 256 19.0 / 15.2, 4 x 128 17.2 / 11.5, 32 x 128 95 / 29.6, 8 x 512 188 / 61)
   const int flash_qw = 8 * 2 * (16 / p.gp);
   const long flash_wgs = (long)num_seqs * ((max_query_len + flash_qw - 1) / flash_qw) * num_kv_heads;
   if ((!kv_fp8 || head_size == 128) && max_query_len >= 32 &&
-      (max_query_len >= env_int("MI355Q_PREFILL_FLASH_MIN", 512) || flash_wgs >= env_int("MI355Q_PREFILL_FLASH_WGS", 64))) {
+      (max_query_len >= env_int("MI355Q_PREFILL_FLASH_MIN", 320) || flash_wgs >= env_int("MI355Q_PREFILL_FLASH_WGS", 64))) {
     if (dtype == MI355Q_BF16) return launch_prefill_flash<BF16>(p, head_size, kv_fp8, max_query_len, (hipStream_t)stream);
     return launch_prefill_flash<FP16>(p, head_size, kv_fp8, max_query_len, (hipStream_t)stream);
   }
