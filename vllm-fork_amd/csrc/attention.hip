@@ -15,6 +15,7 @@
 // tmp_out / exp_sums / max_logits and a second kernel merges partitions.
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 
@@ -44,6 +45,7 @@ struct PAParams {
   int varlen;          // 0: decode rows only, 1: every row, several query tokens per block
   int qblocks_per_seq; // varlen: ceil(max_query_len / QB)
   int gp;              // columns per query token (power of two >= group size)
+  int bs_shift;        // log2(bs) when the block size is a power of two, else -1
   // fused decode step (FUSED kernels): q points into the qkv projection output, the new
   // token's k/v sit k_off / v_off elements after the row start; NeoX RoPE over the whole head
   const int64_t* positions;
@@ -732,9 +734,9 @@ constexpr int PF_NW = 8;          // waves per workgroup (two per SIMD)
 // loaded to match.  V: a lane's piece is tokens 16 kq .. 16 kq + 15 of the tile, its halves feed the two 32-token
 // products, so row i of token tile T is token 16 (i / 4) + 8 (T / 2) + 4 (T % 2) + i % 4 there.
 // PF_CTL = column tiles per wave: 2 (64 query tokens x 4 heads per workgroup, one workgroup per CU) or 1 (32 tokens,
-// two workgroups per CU).
+// two workgroups per CU: the second launch bound is waves per SIMD, four of them fit 128 registers each).
 template <typename DT, int HEAD, bool KVFP8, int PF_CTL>
-__global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 2 : 1) void prefill_flash_kernel(const PAParams p) {
+__global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 4 : 2) void prefill_flash_kernel(const PAParams p) {
   constexpr int DS = HEAD / 32, DTILES = HEAD / 16;
   constexpr int KI = KVFP8 ? 4 * DS / 2 : 4 * DS, VI = KVFP8 ? DTILES : 2 * DTILES;     // LDS-DMA operations per stage
   constexpr int K_BYTES = KI * 1024, V_BYTES = VI * 1024, STAGE = K_BYTES + V_BYTES;
@@ -789,6 +791,8 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 2 : 1) void prefill_flash
   const float kscale = KVFP8 ? *p.k_scale : 1.0f, vscale = KVFP8 ? *p.v_scale : 1.0f;
   const float c2 = p.scale * kscale * 1.44269504088896f;   // logits in the base-2 domain
   const float slope2 = (p.alibi ? p.alibi[kvh * g + min(hi, g - 1)] : 0.f) * 1.44269504088896f;
+  // ALiBi slope per position step, in units of the raw logit (it is multiplied by c2 with the logit)
+  const float slope_raw = p.alibi ? p.alibi[kvh * g + min(hi, g - 1)] / (p.scale * kscale) : 0.f;
   // context of the wave's first query token (0: the wave has none)
   const int wq0 = q0 + wave * PF_CTL * QB;
   const int wave_min_ctx = wq0 < qlen ? seq_len - qlen + wq0 + 1 : 0;
@@ -797,6 +801,10 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 2 : 1) void prefill_flash
   // idx = s2 * DTILES + dt (this lane: head dim 16 dt + col, tokens 8 kq .. 8 kq + 7 of group s2); a wave takes
   // idx = wave, wave + PF_NW, ...  Tokens past the sequence read the piece that holds its last token (valid
   // memory; their logits are masked, their V forced to zero).
+  // block index of a token: a shift -- this kernel is launched for power-of-two block sizes only (an integer division
+  // costs about twenty vector instructions, four times per wave and tile)
+  const int bs_shift = p.bs_shift, bs_mask = p.bs - 1;
+  auto blk_of = [&](int tok) { return tok >> bs_shift; };
   auto stage = [&](int tile, int buf) {
     unsigned char* st = kv + buf * STAGE;
     const int t0 = tile * PF_KV;
@@ -805,8 +813,9 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 2 : 1) void prefill_flash
       const int idx = wave + PF_NW * n;
       const int T = KVFP8 ? idx / (DS / 2) : idx / DS, dc = KVFP8 ? idx % (DS / 2) : idx % DS;   // token tile, 16-byte dim piece
       const int tok = min(t0 + row_tok(T, col), last_tok);
-      const int blk = table[tok / p.bs];
-      const unsigned char* src = kc + ((size_t)blk * p.kv_block_stride) * EB + ((size_t)(dc * 4 + kq) * p.bs + tok % p.bs) * 16;
+      const int bi = blk_of(tok), bo = tok & bs_mask;
+      const int blk = table[bi];
+      const unsigned char* src = kc + ((size_t)blk * p.kv_block_stride) * EB + ((size_t)(dc * 4 + kq) * p.bs + bo) * 16;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                        (void __attribute__((address_space(3)))*)(st + idx * 1024), 16, 0, 0);
     }
@@ -815,8 +824,9 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 2 : 1) void prefill_flash
       const int idx = wave + PF_NW * n;
       const int s2 = KVFP8 ? 0 : idx / DTILES, dt = idx % DTILES;
       const int tok = KVFP8 ? min(t0 + 16 * kq, last_tok & ~15) : min(t0 + 32 * s2 + 8 * kq, last_tok & ~7);
-      const int blk = table[tok / p.bs];
-      const unsigned char* src = vc + ((size_t)blk * p.kv_block_stride + (size_t)(dt * 16 + col) * p.bs + tok % p.bs) * EB;
+      const int bi = blk_of(tok), bo = tok & bs_mask;
+      const int blk = table[bi];
+      const unsigned char* src = vc + ((size_t)blk * p.kv_block_stride + (size_t)(dt * 16 + col) * p.bs + bo) * EB;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                        (void __attribute__((address_space(3)))*)(st + K_BYTES + idx * 1024), 16, 0, 0);
     }
@@ -868,109 +878,232 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 2 : 1) void prefill_flash
         }
       }
     }
-    // ---- running softmax per column, in the base-2 domain (scale * log2 e folded into one multiply-add) -----
-    // Tiles wholly inside the context of the wave's first query token need no mask, and without ALiBi the
-    // logit, the shift by the maximum and the exponent's scaling are one fma + one v_exp per element.
-    u32x4 pf[PF_CTL][2];
-    const bool plain = !p.alibi && t0 + PF_KV <= wave_min_ctx;   // wave-uniform
-    bool rescale = false;
-    float alpha[PF_CTL];
-#pragma unroll
-    for (int c = 0; c < PF_CTL; c++) {
-      float tmax = -INFINITY;
-      if (plain) {
-#pragma unroll
-        for (int T = 0; T < 4; T++)
-          tmax = fmaxf(tmax, fmaxf(fmaxf(sv[c][T][0], sv[c][T][1]), fmaxf(sv[c][T][2], sv[c][T][3])));
-        tmax *= c2;
-      } else {
-#pragma unroll
-        for (int T = 0; T < 4; T++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int tok = t0 + row_tok(T, 4 * kq) + r;
-            float v = sv[c][T][r] * c2 + slope2 * (float)(tok - ctx_c[c] + 1);
-            v = tok < ctx_c[c] ? v : -INFINITY;
-            sv[c][T][r] = v;
-            tmax = fmaxf(tmax, v);
-          }
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float mnew = fmaxf(mrun[c], tmax);
-      const float mref = mnew == -INFINITY ? 0.f : mnew;
-      alpha[c] = mrun[c] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mrun[c] - mref);
-      rescale |= mnew != mrun[c];
-      mrun[c] = mnew;
-      float ls = 0.f;
-#pragma unroll
-      for (int T = 0; T < 4; T++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float e = plain ? __builtin_amdgcn_exp2f(__builtin_fmaf(sv[c][T][r], c2, -mref)) : __builtin_amdgcn_exp2f(sv[c][T][r] - mref);
-          sv[c][T][r] = e;
-          ls += e;
+    // The 32-token form keeps masks and tail handling as selects inside one straight-line block (124 registers:
+    // two workgroups per CU); the 64-token form takes them out of the common path with wave-uniform branches.
+    if constexpr (PF_CTL == 1) {
+      // ---- running softmax per column, in the base-2 domain (scale * log2 e folded into one multiply-add) -----
+      // Tiles wholly inside the context of the wave's first query token need no mask, and without ALiBi the
+      // logit, the shift by the maximum and the exponent's scaling are one fma + one v_exp per element.
+      u32x4 pf[PF_CTL][2];
+      const bool plain = !p.alibi && t0 + PF_KV <= wave_min_ctx;   // wave-uniform
+      bool rescale = false;
+      float alpha[PF_CTL];
+  #pragma unroll
+      for (int c = 0; c < PF_CTL; c++) {
+        float tmax = -INFINITY;
+        if (plain) {
+  #pragma unroll
+          for (int T = 0; T < 4; T++)
+            tmax = fmaxf(tmax, fmaxf(fmaxf(sv[c][T][0], sv[c][T][1]), fmaxf(sv[c][T][2], sv[c][T][3])));
+          tmax *= c2;
+        } else {
+  #pragma unroll
+          for (int T = 0; T < 4; T++)
+  #pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int tok = t0 + row_tok(T, 4 * kq) + r;
+              float v = sv[c][T][r] * c2 + slope2 * (float)(tok - ctx_c[c] + 1);
+              v = tok < ctx_c[c] ? v : -INFINITY;
+              sv[c][T][r] = v;
+              tmax = fmaxf(tmax, v);
+            }
         }
-      lrun[c] = lrun[c] * alpha[c] + ls;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        pf[c][s2][0] = pack2<DT>(sv[c][2 * s2][0], sv[c][2 * s2][1]);
-        pf[c][s2][1] = pack2<DT>(sv[c][2 * s2][2], sv[c][2 * s2][3]);
-        pf[c][s2][2] = pack2<DT>(sv[c][2 * s2 + 1][0], sv[c][2 * s2 + 1][1]);
-        pf[c][s2][3] = pack2<DT>(sv[c][2 * s2 + 1][2], sv[c][2 * s2 + 1][3]);
-      }
-    }
-    if (__builtin_amdgcn_ballot_w64(rescale) != 0) {   // some column's maximum moved: rescale what has been summed
-#pragma unroll
-      for (int c = 0; c < PF_CTL; c++)
-#pragma unroll
-        for (int dt = 0; dt < DTILES; dt++) o[c][dt] *= alpha[c];
-    }
-    // ---- O^T += V^T P^T --------------------------------------------------------------------------
-    const bool ragged = t0 + PF_KV > seq_len;   // the tile reaches past the sequence: unwritten cache memory
-    auto tail_mask = [&](int first_tok, uint32_t (&vm)[4]) {   // the lane's 8 tokens from first_tok on
-      const int nv = min(max(seq_len - first_tok, 0), 8);
-#pragma unroll
-      for (int e = 0; e < 4; e++) vm[e] = nv >= 2 * e + 2 ? 0xffffffffu : (nv == 2 * e + 1 ? 0x0000ffffu : 0u);
-    };
-    if constexpr (!KVFP8) {
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        uint32_t vm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        if (ragged) tail_mask(t0 + 32 * s2 + 8 * kq, vm);
-#pragma unroll
-        for (int dt = 0; dt < DTILES; dt++) {
-          u32x4 vf = *reinterpret_cast<const u32x4*>(st + K_BYTES + (s2 * DTILES + dt) * 1024 + 16 * lane);
-          if (ragged) {
-            // a group that starts past the sequence was fetched from the piece of the last token: all zero here
-            vf[0] &= vm[0]; vf[1] &= vm[1]; vf[2] &= vm[2]; vf[3] &= vm[3];
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrun[c], tmax);
+        const float mref = mnew == -INFINITY ? 0.f : mnew;
+        alpha[c] = mrun[c] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mrun[c] - mref);
+        rescale |= mnew != mrun[c];
+        mrun[c] = mnew;
+        float ls = 0.f;
+  #pragma unroll
+        for (int T = 0; T < 4; T++)
+  #pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float e = plain ? __builtin_amdgcn_exp2f(__builtin_fmaf(sv[c][T][r], c2, -mref)) : __builtin_amdgcn_exp2f(sv[c][T][r] - mref);
+            sv[c][T][r] = e;
+            ls += e;
           }
-#pragma unroll
-          for (int c = 0; c < PF_CTL; c++) o[c][dt] = mfma16<DT>(vf, pf[c][s2], o[c][dt]);
+        lrun[c] = lrun[c] * alpha[c] + ls;
+  #pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          pf[c][s2][0] = pack2<DT>(sv[c][2 * s2][0], sv[c][2 * s2][1]);
+          pf[c][s2][1] = pack2<DT>(sv[c][2 * s2][2], sv[c][2 * s2][3]);
+          pf[c][s2][2] = pack2<DT>(sv[c][2 * s2 + 1][0], sv[c][2 * s2 + 1][1]);
+          pf[c][s2][3] = pack2<DT>(sv[c][2 * s2 + 1][2], sv[c][2 * s2 + 1][3]);
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(rescale) != 0) {   // some column's maximum moved: rescale what has been summed
+  #pragma unroll
+        for (int c = 0; c < PF_CTL; c++)
+  #pragma unroll
+          for (int dt = 0; dt < DTILES; dt++) o[c][dt] *= alpha[c];
+      }
+      // ---- O^T += V^T P^T --------------------------------------------------------------------------
+      const bool ragged = t0 + PF_KV > seq_len;   // the tile reaches past the sequence: unwritten cache memory
+      auto tail_mask = [&](int first_tok, uint32_t (&vm)[4]) {   // the lane's 8 tokens from first_tok on
+        const int nv = min(max(seq_len - first_tok, 0), 8);
+  #pragma unroll
+        for (int e = 0; e < 4; e++) vm[e] = nv >= 2 * e + 2 ? 0xffffffffu : (nv == 2 * e + 1 ? 0x0000ffffu : 0u);
+      };
+      if constexpr (!KVFP8) {
+  #pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          uint32_t vm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+          if (ragged) tail_mask(t0 + 32 * s2 + 8 * kq, vm);
+  #pragma unroll
+          for (int dt = 0; dt < DTILES; dt++) {
+            u32x4 vf = *reinterpret_cast<const u32x4*>(st + K_BYTES + (s2 * DTILES + dt) * 1024 + 16 * lane);
+            if (ragged) {
+              // a group that starts past the sequence was fetched from the piece of the last token: all zero here
+              vf[0] &= vm[0]; vf[1] &= vm[1]; vf[2] &= vm[2]; vf[3] &= vm[3];
+            }
+  #pragma unroll
+            for (int c = 0; c < PF_CTL; c++) o[c][dt] = mfma16<DT>(vf, pf[c][s2], o[c][dt]);
+          }
+        }
+      } else {
+        uint32_t vm0[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        uint32_t vm1[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        if (ragged) {
+          tail_mask(t0 + 16 * kq, vm0);
+          tail_mask(t0 + 16 * kq + 8, vm1);
+        }
+  #pragma unroll
+        for (int dt = 0; dt < DTILES; dt++) {
+          const u32x4 raw = *reinterpret_cast<const u32x4*>(st + K_BYTES + dt * 1024 + 16 * lane);
+          const u32x2 a0 = fp8x4_to_h16<DT>(raw[0]), a1 = fp8x4_to_h16<DT>(raw[1]);
+          const u32x2 b0 = fp8x4_to_h16<DT>(raw[2]), b1 = fp8x4_to_h16<DT>(raw[3]);
+          u32x4 v0 = u32x4{a0[0], a0[1], a1[0], a1[1]}, v1 = u32x4{b0[0], b0[1], b1[0], b1[1]};
+          if (ragged) {
+            v0[0] &= vm0[0]; v0[1] &= vm0[1]; v0[2] &= vm0[2]; v0[3] &= vm0[3];
+            v1[0] &= vm1[0]; v1[1] &= vm1[1]; v1[2] &= vm1[2]; v1[3] &= vm1[3];
+          }
+  #pragma unroll
+          for (int c = 0; c < PF_CTL; c++) {
+            o[c][dt] = mfma16<DT>(v0, pf[c][0], o[c][dt]);
+            o[c][dt] = mfma16<DT>(v1, pf[c][1], o[c][dt]);
+          }
         }
       }
     } else {
-      uint32_t vm0[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-      uint32_t vm1[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-      if (ragged) {
-        tail_mask(t0 + 16 * kq, vm0);
-        tail_mask(t0 + 16 * kq + 8, vm1);
+      // ---- running softmax per column, in the base-2 domain (scale * log2 e folded into one multiply-add) -----
+      // Tiles wholly inside the context of the wave's first query token need no mask, and without ALiBi the
+      // logit, the shift by the maximum and the exponent's scaling are one fma + one v_exp per element.
+      u32x4 pf[PF_CTL][2];
+      const bool plain = !p.alibi && t0 + PF_KV <= wave_min_ctx;   // wave-uniform
+      bool rescale = false;
+      float alpha[PF_CTL];
+      // Tiles that touch the causal diagonal (or carry ALiBi) are masked in the raw-logit domain first, under a branch
+      // the whole wave takes or skips (the empty asm keeps the compiler from turning it into selects that every tile
+      // would execute); after that one arithmetic serves both kinds of tile: masked logits are -inf, and
+      // exp2(-inf * c2 - m) = 0.
+      if (!plain) {
+        asm volatile("");
+  #pragma unroll
+        for (int c = 0; c < PF_CTL; c++)
+  #pragma unroll
+          for (int T = 0; T < 4; T++)
+  #pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int tok = t0 + row_tok(T, 4 * kq) + r;
+              const float v = sv[c][T][r] + slope_raw * (float)(tok - ctx_c[c] + 1);
+              sv[c][T][r] = tok < ctx_c[c] ? v : -INFINITY;
+            }
       }
-#pragma unroll
-      for (int dt = 0; dt < DTILES; dt++) {
-        const u32x4 raw = *reinterpret_cast<const u32x4*>(st + K_BYTES + dt * 1024 + 16 * lane);
-        const u32x2 a0 = fp8x4_to_h16<DT>(raw[0]), a1 = fp8x4_to_h16<DT>(raw[1]);
-        const u32x2 b0 = fp8x4_to_h16<DT>(raw[2]), b1 = fp8x4_to_h16<DT>(raw[3]);
-        u32x4 v0 = u32x4{a0[0], a0[1], a1[0], a1[1]}, v1 = u32x4{b0[0], b0[1], b1[0], b1[1]};
-        if (ragged) {
-          v0[0] &= vm0[0]; v0[1] &= vm0[1]; v0[2] &= vm0[2]; v0[3] &= vm0[3];
-          v1[0] &= vm1[0]; v1[1] &= vm1[1]; v1[2] &= vm1[2]; v1[3] &= vm1[3];
+  #pragma unroll
+      for (int c = 0; c < PF_CTL; c++) {
+        float tmax = -INFINITY;
+  #pragma unroll
+        for (int T = 0; T < 4; T++)
+          tmax = fmaxf(tmax, fmaxf(fmaxf(sv[c][T][0], sv[c][T][1]), fmaxf(sv[c][T][2], sv[c][T][3])));
+        tmax *= c2;
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrun[c], tmax);
+        const float mref = mnew == -INFINITY ? 0.f : mnew;
+        alpha[c] = mrun[c] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mrun[c] - mref);
+        rescale |= mnew != mrun[c];
+        mrun[c] = mnew;
+        float ls = 0.f;
+  #pragma unroll
+        for (int T = 0; T < 4; T++)
+  #pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[c][T][r], c2, -mref));
+            sv[c][T][r] = e;
+            ls += e;
+          }
+        lrun[c] = lrun[c] * alpha[c] + ls;
+  #pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          pf[c][s2][0] = pack2<DT>(sv[c][2 * s2][0], sv[c][2 * s2][1]);
+          pf[c][s2][1] = pack2<DT>(sv[c][2 * s2][2], sv[c][2 * s2][3]);
+          pf[c][s2][2] = pack2<DT>(sv[c][2 * s2 + 1][0], sv[c][2 * s2 + 1][1]);
+          pf[c][s2][3] = pack2<DT>(sv[c][2 * s2 + 1][2], sv[c][2 * s2 + 1][3]);
         }
-#pragma unroll
-        for (int c = 0; c < PF_CTL; c++) {
-          o[c][dt] = mfma16<DT>(v0, pf[c][0], o[c][dt]);
-          o[c][dt] = mfma16<DT>(v1, pf[c][1], o[c][dt]);
+      }
+      if (__builtin_amdgcn_ballot_w64(rescale) != 0) {   // some column's maximum moved: rescale what has been summed
+  #pragma unroll
+        for (int c = 0; c < PF_CTL; c++)
+  #pragma unroll
+          for (int dt = 0; dt < DTILES; dt++) o[c][dt] *= alpha[c];
+      }
+      // ---- O^T += V^T P^T --------------------------------------------------------------------------
+      const bool ragged = t0 + PF_KV > seq_len;   // the tile reaches past the sequence: unwritten cache memory
+      auto tail_mask = [&](int first_tok, uint32_t (&vm)[4]) {   // the lane's 8 tokens from first_tok on
+        const int nv = min(max(seq_len - first_tok, 0), 8);
+  #pragma unroll
+        for (int e = 0; e < 4; e++) vm[e] = nv >= 2 * e + 2 ? 0xffffffffu : (nv == 2 * e + 1 ? 0x0000ffffu : 0u);
+      };
+      auto pv = [&](auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        if constexpr (!KVFP8) {
+  #pragma unroll
+          for (int s2 = 0; s2 < 2; s2++) {
+            uint32_t vm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if constexpr (MASKED) tail_mask(t0 + 32 * s2 + 8 * kq, vm);
+  #pragma unroll
+            for (int dt = 0; dt < DTILES; dt++) {
+              u32x4 vf = *reinterpret_cast<const u32x4*>(st + K_BYTES + (s2 * DTILES + dt) * 1024 + 16 * lane);
+              if constexpr (MASKED) {
+                // a group that starts past the sequence was fetched from the piece of the last token: all zero here
+                vf[0] &= vm[0]; vf[1] &= vm[1]; vf[2] &= vm[2]; vf[3] &= vm[3];
+              }
+  #pragma unroll
+              for (int c = 0; c < PF_CTL; c++) o[c][dt] = mfma16<DT>(vf, pf[c][s2], o[c][dt]);
+            }
+          }
+        } else {
+          uint32_t vm0[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+          uint32_t vm1[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+          if constexpr (MASKED) {
+            tail_mask(t0 + 16 * kq, vm0);
+            tail_mask(t0 + 16 * kq + 8, vm1);
+          }
+  #pragma unroll
+          for (int dt = 0; dt < DTILES; dt++) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(st + K_BYTES + dt * 1024 + 16 * lane);
+            const u32x2 a0 = fp8x4_to_h16<DT>(raw[0]), a1 = fp8x4_to_h16<DT>(raw[1]);
+            const u32x2 b0 = fp8x4_to_h16<DT>(raw[2]), b1 = fp8x4_to_h16<DT>(raw[3]);
+            u32x4 v0 = u32x4{a0[0], a0[1], a1[0], a1[1]}, v1 = u32x4{b0[0], b0[1], b1[0], b1[1]};
+            if constexpr (MASKED) {
+              v0[0] &= vm0[0]; v0[1] &= vm0[1]; v0[2] &= vm0[2]; v0[3] &= vm0[3];
+              v1[0] &= vm1[0]; v1[1] &= vm1[1]; v1[2] &= vm1[2]; v1[3] &= vm1[3];
+            }
+  #pragma unroll
+            for (int c = 0; c < PF_CTL; c++) {
+              o[c][dt] = mfma16<DT>(v0, pf[c][0], o[c][dt]);
+              o[c][dt] = mfma16<DT>(v1, pf[c][1], o[c][dt]);
+            }
+          }
         }
+      };
+      if (ragged) {   // the sequence's last tile only: a branch of its own, so that no other tile pays for the masks
+        asm volatile("");
+        pv(std::true_type{});
+      } else {
+        pv(std::false_type{});
       }
     }
   }
@@ -1008,19 +1141,16 @@ static int launch_prefill_flash_ctl(const PAParams& p_in, int head_size, int kv_
 }
 
 // 32 or 64 query tokens per workgroup.  The narrow form reads every K/V tile twice as often but brings twice the
-// workgroups, two resident per CU, and halves the longest one under the causal mask.  Measured (32 query / 8 kv heads
-// of 128; us, 64-token form -> 32-token form): 1 x 512 tokens 33.5 -> 24.8, 1 x 1024 58.5 -> 44.1, 1 x 2048 112 -> 91,
-// 1 x 3072 166 -> 157, 1 x 4096 237 -> 259; 8 x 128 16.3 -> 12.9, 32 x 128 35.9 -> 29.3, 64 x 128 67.9 -> 56.1,
-// 32 x 256 88.7 -> 74.2, 8 x 512 68.9 -> 59.7, 16 x 512 120 -> 106; but 4 x 512 35.6 -> 38.1, 2 x 1024 60.8 -> 67.4,
-// 2 x 2048 136 -> 152, 32 x 1024 662 -> 662.  Taken where the wide form leaves CUs idle, for short prompts in
-// batches beyond one round, and for a single prompt up to about 3000 tokens (MI355Q_PREFILL_FLASH_CTL = 1 / 2 forces).
+// workgroups, two resident per CU, and halves the longest one under the causal mask.  Taken where the wide form
+// leaves CUs idle, for short prompts in batches beyond one round, and for a single prompt that makes at most one
+// round of the wide form; measurements in the table of the selection below (MI355Q_PREFILL_FLASH_CTL = 1 / 2 forces).
 template <typename DT>
 static int launch_prefill_flash(const PAParams& p_in, int head_size, int kv_fp8, int max_qlen, hipStream_t stream) {
   const int qw2 = PF_NW * 2 * (16 / p_in.gp);
   const long wgs2 = (long)p_in.num_seqs * ((max_qlen + qw2 - 1) / qw2) * p_in.num_kv_heads;
   const int forced = env_int("MI355Q_PREFILL_FLASH_CTL", 0);
   const bool narrow = forced ? forced == 1
-                             : (wgs2 < 256 || (max_qlen <= 512 && wgs2 > 256) || (p_in.num_seqs == 1 && wgs2 <= 384));
+                             : (wgs2 < 256 || (max_qlen <= 512 && wgs2 > 256) || (p_in.num_seqs == 1 && wgs2 <= 256));
   if (narrow) return launch_prefill_flash_ctl<DT, 1>(p_in, head_size, kv_fp8, max_qlen, stream);
   return launch_prefill_flash_ctl<DT, 2>(p_in, head_size, kv_fp8, max_qlen, stream);
 }
@@ -1075,6 +1205,7 @@ static int pa_common(PAParams& p, int head_size, int block_size, int max_seq_len
   int gp = 1;
   while (gp < g) gp <<= 1;
   p.gp = gp;
+  p.bs_shift = (block_size & (block_size - 1)) == 0 ? __builtin_ctz((unsigned)block_size) : -1;
   return 0;
 }
 
@@ -1130,12 +1261,15 @@ extern "C" int mi355q_paged_prefill_attention(
   // long queries over a 16-bit cache: the running-softmax kernel (K/V tiles shared by 8 column tiles through LDS)
   // ... when the query is long or the batch brings enough workgroups: a single short prompt is a handful of
   // workgroups walking their tiles one after the other, and the partitioned kernel's many small workgroups
-  // finish sooner (us, partitioned / running in the form launch_prefill_flash picks: 1 x 128 tokens 14.9 / 14.9,
-  // 1 x 256 14.6 / 15.0, 1 x 384 25.8 / 19.6, 1 x 512 37.1 / 24.6, 1 x 1024 94 / 44, 1 x 2048 295 / 93;
-  // 2 x 128 12.2 / 11.5, 2 x 256 19.0 / 15.2, 4 x 128 17.2 / 11.5, 32 x 128 95 / 29.6, 8 x 512 188 / 61)
+  // finish sooner (us, partitioned / running in the form launch_prefill_flash picks: 1 x 128 tokens 13.5 / 11-15,
+  // 1 x 256 13.3 / 14.6, 1 x 384 27 / 17.7, 1 x 512 37 / 22.3, 1 x 1024 94 / 38.8, 1 x 2048 295 / 83.6,
+  // 1 x 4096 1140 / 197; 2 x 128 12.2 / 11.5, 4 x 128 17.2 / 11.5, 32 x 128 95 / 28.4, 8 x 512 188 / 56,
+  // 32 x 1024 3120 / 574.  The two forms of the running-softmax kernel, 64- / 32-token: 1 x 512 29.3 / 22.6,
+  // 1 x 1024 49.6 / 39.7, 1 x 2048 94.8 / 86.8, 1 x 3072 138 / 142, 1 x 4096 201 / 230, 2 x 1024 52.4 / 60.8,
+  // 4 x 512 31.8 / 36.3, 8 x 512 60.0 / 56.0, 32 x 128 34.6 / 28.4, 32 x 256 81.3 / 67.7, 32 x 1024 572 / 621)
   const int flash_qw = 8 * 2 * (16 / p.gp);
   const long flash_wgs = (long)num_seqs * ((max_query_len + flash_qw - 1) / flash_qw) * num_kv_heads;
-  if ((!kv_fp8 || head_size == 128) && max_query_len >= 32 &&
+  if ((!kv_fp8 || head_size == 128) && max_query_len >= 32 && p.bs_shift >= 0 &&
       (max_query_len >= env_int("MI355Q_PREFILL_FLASH_MIN", 320) || flash_wgs >= env_int("MI355Q_PREFILL_FLASH_WGS", 64))) {
     if (dtype == MI355Q_BF16) return launch_prefill_flash<BF16>(p, head_size, kv_fp8, max_query_len, (hipStream_t)stream);
     return launch_prefill_flash<FP16>(p, head_size, kv_fp8, max_query_len, (hipStream_t)stream);
