@@ -888,18 +888,18 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 4 : 2) void prefill_flash
       const bool plain = !p.alibi && t0 + PF_KV <= wave_min_ctx;   // wave-uniform
       bool rescale = false;
       float alpha[PF_CTL];
-  #pragma unroll
+#pragma unroll
       for (int c = 0; c < PF_CTL; c++) {
         float tmax = -INFINITY;
         if (plain) {
-  #pragma unroll
+#pragma unroll
           for (int T = 0; T < 4; T++)
             tmax = fmaxf(tmax, fmaxf(fmaxf(sv[c][T][0], sv[c][T][1]), fmaxf(sv[c][T][2], sv[c][T][3])));
           tmax *= c2;
         } else {
-  #pragma unroll
+#pragma unroll
           for (int T = 0; T < 4; T++)
-  #pragma unroll
+#pragma unroll
             for (int r = 0; r < 4; r++) {
               const int tok = t0 + row_tok(T, 4 * kq) + r;
               float v = sv[c][T][r] * c2 + slope2 * (float)(tok - ctx_c[c] + 1);
@@ -916,16 +916,16 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 4 : 2) void prefill_flash
         rescale |= mnew != mrun[c];
         mrun[c] = mnew;
         float ls = 0.f;
-  #pragma unroll
+#pragma unroll
         for (int T = 0; T < 4; T++)
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < 4; r++) {
             const float e = plain ? __builtin_amdgcn_exp2f(__builtin_fmaf(sv[c][T][r], c2, -mref)) : __builtin_amdgcn_exp2f(sv[c][T][r] - mref);
             sv[c][T][r] = e;
             ls += e;
           }
         lrun[c] = lrun[c] * alpha[c] + ls;
-  #pragma unroll
+#pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
           pf[c][s2][0] = pack2<DT>(sv[c][2 * s2][0], sv[c][2 * s2][1]);
           pf[c][s2][1] = pack2<DT>(sv[c][2 * s2][2], sv[c][2 * s2][3]);
@@ -934,31 +934,31 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 4 : 2) void prefill_flash
         }
       }
       if (__builtin_amdgcn_ballot_w64(rescale) != 0) {   // some column's maximum moved: rescale what has been summed
-  #pragma unroll
+#pragma unroll
         for (int c = 0; c < PF_CTL; c++)
-  #pragma unroll
+#pragma unroll
           for (int dt = 0; dt < DTILES; dt++) o[c][dt] *= alpha[c];
       }
       // ---- O^T += V^T P^T --------------------------------------------------------------------------
       const bool ragged = t0 + PF_KV > seq_len;   // the tile reaches past the sequence: unwritten cache memory
       auto tail_mask = [&](int first_tok, uint32_t (&vm)[4]) {   // the lane's 8 tokens from first_tok on
         const int nv = min(max(seq_len - first_tok, 0), 8);
-  #pragma unroll
+#pragma unroll
         for (int e = 0; e < 4; e++) vm[e] = nv >= 2 * e + 2 ? 0xffffffffu : (nv == 2 * e + 1 ? 0x0000ffffu : 0u);
       };
       if constexpr (!KVFP8) {
-  #pragma unroll
+#pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
           uint32_t vm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
           if (ragged) tail_mask(t0 + 32 * s2 + 8 * kq, vm);
-  #pragma unroll
+#pragma unroll
           for (int dt = 0; dt < DTILES; dt++) {
             u32x4 vf = *reinterpret_cast<const u32x4*>(st + K_BYTES + (s2 * DTILES + dt) * 1024 + 16 * lane);
             if (ragged) {
               // a group that starts past the sequence was fetched from the piece of the last token: all zero here
               vf[0] &= vm[0]; vf[1] &= vm[1]; vf[2] &= vm[2]; vf[3] &= vm[3];
             }
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c < PF_CTL; c++) o[c][dt] = mfma16<DT>(vf, pf[c][s2], o[c][dt]);
           }
         }
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 4 : 2) void prefill_flash
           tail_mask(t0 + 16 * kq, vm0);
           tail_mask(t0 + 16 * kq + 8, vm1);
         }
-  #pragma unroll
+#pragma unroll
         for (int dt = 0; dt < DTILES; dt++) {
           const u32x4 raw = *reinterpret_cast<const u32x4*>(st + K_BYTES + dt * 1024 + 16 * lane);
           const u32x2 a0 = fp8x4_to_h16<DT>(raw[0]), a1 = fp8x4_to_h16<DT>(raw[1]);
@@ -979,7 +979,7 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 4 : 2) void prefill_flash
             v0[0] &= vm0[0]; v0[1] &= vm0[1]; v0[2] &= vm0[2]; v0[3] &= vm0[3];
             v1[0] &= vm1[0]; v1[1] &= vm1[1]; v1[2] &= vm1[2]; v1[3] &= vm1[3];
           }
-  #pragma unroll
+#pragma unroll
           for (int c = 0; c < PF_CTL; c++) {
             o[c][dt] = mfma16<DT>(v0, pf[c][0], o[c][dt]);
             o[c][dt] = mfma16<DT>(v1, pf[c][1], o[c][dt]);
@@ -1000,21 +1000,21 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 4 : 2) void prefill_flash
       // exp2(-inf * c2 - m) = 0.
       if (!plain) {
         asm volatile("");
-  #pragma unroll
+#pragma unroll
         for (int c = 0; c < PF_CTL; c++)
-  #pragma unroll
+#pragma unroll
           for (int T = 0; T < 4; T++)
-  #pragma unroll
+#pragma unroll
             for (int r = 0; r < 4; r++) {
               const int tok = t0 + row_tok(T, 4 * kq) + r;
               const float v = sv[c][T][r] + slope_raw * (float)(tok - ctx_c[c] + 1);
               sv[c][T][r] = tok < ctx_c[c] ? v : -INFINITY;
             }
       }
-  #pragma unroll
+#pragma unroll
       for (int c = 0; c < PF_CTL; c++) {
         float tmax = -INFINITY;
-  #pragma unroll
+#pragma unroll
         for (int T = 0; T < 4; T++)
           tmax = fmaxf(tmax, fmaxf(fmaxf(sv[c][T][0], sv[c][T][1]), fmaxf(sv[c][T][2], sv[c][T][3])));
         tmax *= c2;
@@ -1026,16 +1026,16 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 4 : 2) void prefill_flash
         rescale |= mnew != mrun[c];
         mrun[c] = mnew;
         float ls = 0.f;
-  #pragma unroll
+#pragma unroll
         for (int T = 0; T < 4; T++)
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < 4; r++) {
             const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[c][T][r], c2, -mref));
             sv[c][T][r] = e;
             ls += e;
           }
         lrun[c] = lrun[c] * alpha[c] + ls;
-  #pragma unroll
+#pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
           pf[c][s2][0] = pack2<DT>(sv[c][2 * s2][0], sv[c][2 * s2][1]);
           pf[c][s2][1] = pack2<DT>(sv[c][2 * s2][2], sv[c][2 * s2][3]);
@@ -1044,33 +1044,33 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 4 : 2) void prefill_flash
         }
       }
       if (__builtin_amdgcn_ballot_w64(rescale) != 0) {   // some column's maximum moved: rescale what has been summed
-  #pragma unroll
+#pragma unroll
         for (int c = 0; c < PF_CTL; c++)
-  #pragma unroll
+#pragma unroll
           for (int dt = 0; dt < DTILES; dt++) o[c][dt] *= alpha[c];
       }
       // ---- O^T += V^T P^T --------------------------------------------------------------------------
       const bool ragged = t0 + PF_KV > seq_len;   // the tile reaches past the sequence: unwritten cache memory
       auto tail_mask = [&](int first_tok, uint32_t (&vm)[4]) {   // the lane's 8 tokens from first_tok on
         const int nv = min(max(seq_len - first_tok, 0), 8);
-  #pragma unroll
+#pragma unroll
         for (int e = 0; e < 4; e++) vm[e] = nv >= 2 * e + 2 ? 0xffffffffu : (nv == 2 * e + 1 ? 0x0000ffffu : 0u);
       };
       auto pv = [&](auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         if constexpr (!KVFP8) {
-  #pragma unroll
+#pragma unroll
           for (int s2 = 0; s2 < 2; s2++) {
             uint32_t vm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
             if constexpr (MASKED) tail_mask(t0 + 32 * s2 + 8 * kq, vm);
-  #pragma unroll
+#pragma unroll
             for (int dt = 0; dt < DTILES; dt++) {
               u32x4 vf = *reinterpret_cast<const u32x4*>(st + K_BYTES + (s2 * DTILES + dt) * 1024 + 16 * lane);
               if constexpr (MASKED) {
                 // a group that starts past the sequence was fetched from the piece of the last token: all zero here
                 vf[0] &= vm[0]; vf[1] &= vm[1]; vf[2] &= vm[2]; vf[3] &= vm[3];
               }
-  #pragma unroll
+#pragma unroll
               for (int c = 0; c < PF_CTL; c++) o[c][dt] = mfma16<DT>(vf, pf[c][s2], o[c][dt]);
             }
           }
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 4 : 2) void prefill_flash
             tail_mask(t0 + 16 * kq, vm0);
             tail_mask(t0 + 16 * kq + 8, vm1);
           }
-  #pragma unroll
+#pragma unroll
           for (int dt = 0; dt < DTILES; dt++) {
             const u32x4 raw = *reinterpret_cast<const u32x4*>(st + K_BYTES + dt * 1024 + 16 * lane);
             const u32x2 a0 = fp8x4_to_h16<DT>(raw[0]), a1 = fp8x4_to_h16<DT>(raw[1]);
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(64 * PF_NW, PF_CTL == 1 ? 4 : 2) void prefill_flash
               v0[0] &= vm0[0]; v0[1] &= vm0[1]; v0[2] &= vm0[2]; v0[3] &= vm0[3];
               v1[0] &= vm1[0]; v1[1] &= vm1[1]; v1[2] &= vm1[2]; v1[3] &= vm1[3];
             }
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c < PF_CTL; c++) {
               o[c][dt] = mfma16<DT>(v0, pf[c][0], o[c][dt]);
               o[c][dt] = mfma16<DT>(v1, pf[c][1], o[c][dt]);
