@@ -781,7 +781,8 @@ def prefill_kernel(request):
 @pytest.mark.parametrize("prefill_kernel", ["partitioned", "running", "running32"], indirect=True)
 @pytest.mark.parametrize("H,KVH,D,bs,fp8", [(8, 2, 128, 16, False), (4, 4, 64, 32, False), (16, 2, 128, 16, True),
                                            (16, 2, 128, 16, False), (4, 2, 128, 64, False), (6, 2, 64, 16, False),
-                                           (32, 8, 128, 16, False)])
+                                           (32, 8, 128, 16, False),
+                                           (8, 2, 128, 48, False)])   # not a power of two: the partitioned kernel serves it
 def test_paged_prefill_attention_vs_oracle(H, KVH, D, bs, fp8, prefill_kernel):
     """Prompt rows: write K/V with reshape_and_cache, attend through the cache, compare with
     dense causal attention of the oracle (and a decode row mixed in)."""
