@@ -2071,6 +2071,17 @@ __global__ __launch_bounds__(512) void w4a16_stream_rows_kernel(const MmParams p
   for (int i = 0; i < CPW; i++) issue_chunk(0, i);
 
   const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
+  // (x & mask) | magic in one instruction per 16-bit pair, constants in registers as in the tiled kernel below
+  uint32_t magic_v = DT::int4_magic, nib_mask = 0x000F000Fu;
+  asm volatile("" : "+v"(magic_v), "+s"(nib_mask));
+  auto expand = [&](uint32_t wd) {
+    u32x4 r;
+    r[0] = (wd & nib_mask) | magic_v;
+    r[1] = ((wd >> 4) & nib_mask) | magic_v;
+    r[2] = ((wd >> 8) & nib_mask) | magic_v;
+    r[3] = ((wd >> 12) & nib_mask) | magic_v;
+    return r;
+  };
   float* mine = red + (size_t)wave * 32 * SW + ml * SW + QW * kq;   // + 16 rt SW + 4 sub
   const int last = cfirst + CPW * bursts - 1;
   for (int burst = 0; burst < bursts; burst++) {
@@ -2105,7 +2116,7 @@ __global__ __launch_bounds__(512) void w4a16_stream_rows_kernel(const MmParams p
 #pragma unroll
         for (int sub = 0; sub < NS; sub++) {
           const int e = ks * NS + sub;
-          const u32x4 wf = dequant_frag<DT>(w[i][e >> 2][e & 3]);
+          const u32x4 wf = expand(w[i][e >> 2][e & 3]);
 #pragma unroll
           for (int rt = 0; rt < RT; rt++) acc[rt][sub] = mfma16<DT>(wf, xc[ks][rt], acc[rt][sub]);
         }
