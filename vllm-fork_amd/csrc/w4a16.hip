@@ -1377,6 +1377,17 @@ __global__ __launch_bounds__(512) void w4a16_rows_kernel(const RowsParams p) {
 #pragma unroll
   for (int i = 0; i < SPB; i++) tot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
+  // (x & mask) | magic in one instruction per 16-bit pair: both constants live in registers (see the ring kernel)
+  uint32_t magic_v = DT::int4_magic, nib_mask = 0x000F000Fu;
+  asm volatile("" : "+v"(magic_v), "+s"(nib_mask));
+  auto expand = [&](uint32_t wd) {
+    u32x4 r;
+    r[0] = (wd & nib_mask) | magic_v;
+    r[1] = ((wd >> 4) & nib_mask) | magic_v;
+    r[2] = ((wd >> 8) & nib_mask) | magic_v;
+    r[3] = ((wd >> 12) & nib_mask) | magic_v;
+    return r;
+  };
   const uint16_t* arow = act + (size_t)min(ml, Mt - 1) * astride + 8 * kq;
 
   for (int burst = 0; burst < p.bursts; burst++) {
@@ -1391,7 +1402,7 @@ __global__ __launch_bounds__(512) void w4a16_rows_kernel(const RowsParams p) {
         const u32x4 bf = *reinterpret_cast<const u32x4*>(arow + ((c - kc0) * 4 + ks) * 32);
         acc1 = mfma16<DT>(ones, bf, acc1);
 #pragma unroll
-        for (int sub = 0; sub < SPB; sub++) acc[sub] = mfma16<DT>(dequant_frag<DT>(w[i][sub][ks]), bf, acc[sub]);
+        for (int sub = 0; sub < SPB; sub++) acc[sub] = mfma16<DT>(expand(w[i][sub][ks]), bf, acc[sub]);
         __builtin_amdgcn_sched_barrier(0);
       }
       // this lane's outputs: channels 16 sub + 4 kq + r of the workgroup's BW
@@ -1680,6 +1691,17 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 1) void w4a16_mm_kernel(const Mm
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) tot[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
+  // (x & mask) | magic in one instruction per 16-bit pair: both constants live in registers (see the ring kernel)
+  uint32_t magic_v = DT::int4_magic, nib_mask = 0x000F000Fu;
+  asm volatile("" : "+v"(magic_v), "+s"(nib_mask));
+  auto expand = [&](uint32_t wd) {
+    u32x4 r;
+    r[0] = (wd & nib_mask) | magic_v;
+    r[1] = ((wd >> 4) & nib_mask) | magic_v;
+    r[2] = ((wd >> 8) & nib_mask) | magic_v;
+    r[3] = ((wd >> 12) & nib_mask) | magic_v;
+    return r;
+  };
 
   for (int c = c0; c < c1; c++) {
     const int cur = (c - c0) & 1;
@@ -1716,7 +1738,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 1) void w4a16_mm_kernel(const Mm
 #pragma unroll
         for (int sub = 0; sub < NS; sub++) {
           const int e = ks * NS + sub;
-          const u32x4 wf = dequant_frag<DT>(wc[j * NS + (e >> 2)][e & 3]);
+          const u32x4 wf = expand(wc[j * NS + (e >> 2)][e & 3]);
 #pragma unroll
           for (int rt = 0; rt < RT; rt++) acc[rt][j * NS + sub] = mfma16<DT>(wf, bf[rt], acc[rt][j * NS + sub]);
         }
