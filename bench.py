@@ -219,6 +219,46 @@ def cpu_baseline_opt125m(budget_s=6.0):
                       "oracle/opt125m.py, batch 1, prompt 32" % steps, "sample_seconds": el}
 
 
+def time_allreduce_16k(dev, reps=200):
+    """The TP exchange of a 70B decode step: sum all-reduce of one [1, 8192] bf16 row (16 KiB) on the default
+    process group.  Eager: `reps` back-to-back calls between two events; captured: the same calls inside one
+    HIP graph, replayed.  Microseconds per all-reduce, (eager, captured or None, capture error or None)."""
+    x = torch.ones(8192, dtype=torch.bfloat16, device=dev)
+    for _ in range(10):
+        torch.distributed.all_reduce(x)
+        x.fill_(1.0)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        torch.distributed.all_reduce(x)
+    b.record()
+    torch.cuda.synchronize()
+    eager = a.elapsed_time(b) * 1e3 / reps
+    captured, err = None, None
+    try:
+        x.fill_(1.0)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(50):
+                    torch.distributed.all_reduce(x)
+            g.replay()
+            s.synchronize()
+            x.fill_(1.0)
+            a.record(s)
+            for _ in range(4):
+                g.replay()
+            b.record(s)
+            s.synchronize()
+        captured = a.elapsed_time(b) * 1e3 / 200
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"[:200]
+    return eager, captured, err
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -228,8 +268,13 @@ def main():
     share = os.environ.get("MI355Q_SHARE_GPU") == "1"
     dev_index = 0 if (world == 1 or share) else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    # MI355Q_FORCE_TP_PATH=1: a process group (RCCL) even at world size 1, and the runner issues its TP
+    # collectives into it -- the one-GPU rehearsal of what every rank of an N > 1 run executes
+    dist_on = world > 1 or os.environ.get("MI355Q_FORCE_TP_PATH") == "1"
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29541"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
         backend = os.environ.get("MI355Q_DIST_BACKEND", "nccl")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -264,19 +309,19 @@ def main():
     ttft = None
     if not args.skip_ttft:
         ts = []
-        for i in range(7):
+        for i in range(20):      # 5 warm-ups + 15 timed iterations (.buildkite/performance-benchmarks/tests/latency-tests.json:8-9)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             runner.prefill(prompt)
             torch.cuda.synchronize()
-            if i >= 2:
+            if i >= 5:
                 ts.append(time.perf_counter() - t0)
         ttft = statistics.median(ts) * 1e3
     else:
         runner.reset(in_len)
 
     # ---- decode ------------------------------------------------------------------------------
-    graph = not args.no_graph and not (world > 1 and torch.distributed.get_backend() == "gloo")
+    graph = not args.no_graph and not (dist_on and torch.distributed.get_backend() == "gloo")
     graph_error = None
     if graph:
         try:
@@ -287,7 +332,7 @@ def main():
                 print(f"[bench] graph capture failed ({graph_error}); running eagerly", file=sys.stderr)
             graph = False
             runner.graph = None
-        if world > 1:   # every rank must take the same path: one eager rank would deadlock the others' replays
+        if dist_on:   # every rank must take the same path: one eager rank would deadlock the others' replays
             flag = torch.tensor([1 if graph else 0], device=dev)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
             if int(flag.item()) == 0 and graph:
@@ -297,7 +342,7 @@ def main():
         runner.decode_step()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
 
     trace = []
@@ -314,7 +359,7 @@ def main():
     if args.tokens_out and rank == 0:
         with open(args.tokens_out, "w") as fh:
             json.dump(trace, fh)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -348,6 +393,11 @@ def main():
         "step_hbm_frac_of_measured_stream_peak": step_bytes / step_s / 1e9 / STREAM_PEAK_GBS,
         "last_token_ids": last_ids[:4],
     }
+    if dist_on and torch.distributed.get_backend() == "nccl":
+        # every rank takes part; latency of the 16 KiB exchange a 70B decode step makes 160 times
+        ar_eager, ar_graph, ar_err = time_allreduce_16k(dev)
+        out["allreduce_us_16k"] = {"eager": ar_eager, "captured": ar_graph, "capture_error": ar_err, "world": world,
+                                   "backend": "nccl (RCCL)"}
     if rank == 0:
         out["roofline"] = time_dominant_kernel(runner, B)
     if rank == 0 and n_gpus == 1 and not args.skip_cpu:
@@ -407,7 +457,7 @@ def main():
             del r2
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

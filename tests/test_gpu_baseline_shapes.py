@@ -76,7 +76,6 @@ def _close(got_bits, want_bits, what, min_equal=0.93):
     step = np.abs(got_bits.astype(np.int32) - want_bits.astype(np.int32))
     assert np.all((step <= 1) | np.isclose(f32(got_bits), f32(want_bits), rtol=0, atol=1e-3)), what
     assert (got_bits == want_bits).mean() > min_equal, what
-    assert (got_bits == want_bits).mean() > min_equal, what
 
 
 def _decode_layer_calls(rng, M, hidden, qkv_n, o_k, gate_up_n, down_k, awq, what):

@@ -1292,6 +1292,32 @@ def test_moe_expert_map_and_sum(monkeypatch):
     assert torch.equal(s, y.float().sum(1).to(torch.bfloat16))
 
 
+def test_moe_grouped_route_when_no_selected_expert_is_local(monkeypatch):
+    """Expert parallelism, a batch none of whose selected experts this rank holds: the grouped route writes no
+    tile, so every row it gathers back is memory no kernel wrote.  The output must be exact zeros (what the rank
+    adds to the reduce-scatter), even when that memory holds NaN."""
+    from mi355q.plugin import fused_experts, moe as moe_mod
+    rng = np.random.default_rng(5)
+    E, H, I, G, T, topk = 6, 1024, 1024, 128, 70, 2
+    def mk(n, k):
+        return (rng.integers(0, 256, size=(2, n, k // 2), dtype=np.uint8),
+                orc.f32_to_h16((0.01 * rng.random((2, n, k // G)) + 0.002).astype(np.float32)))
+    w1, w2 = mk(2 * I, H), mk(H, I)
+    d13 = ops.moe_w4a16_repack(torch.from_numpy(w1[0]).to(DEV), to_dev(w1[1]), None, G, pair_halves=True)
+    d2 = ops.moe_w4a16_repack(torch.from_numpy(w2[0]).to(DEV), to_dev(w2[1]), None, G)
+    emap = torch.tensor([0, 1, -1, -1, -1, -1], dtype=torch.int32, device=DEV)   # this rank holds experts 0 and 1
+    ids = torch.from_numpy(np.stack([2 + rng.permutation(4)[:topk] for _ in range(T)]).astype(np.int32)).to(DEV)
+    tw = torch.from_numpy(rng.random((T, topk)).astype(np.float32)).to(DEV)
+    a = to_dev(orc.f32_to_h16((0.5 * rng.standard_normal((T, H))).astype(np.float32)))
+    monkeypatch.setattr(moe_mod, "FORCE_ROUTE", "grouped")
+    # poison the allocator's free blocks: the route's torch.empty buffers then start out as NaN
+    for _ in range(2):
+        junk = [torch.full((n,), float("nan"), dtype=torch.bfloat16, device=DEV) for n in (1 << 24, 1 << 22, 1 << 20, 1 << 18)]
+        del junk
+        out = fused_experts(a, d13, d2, tw, ids, emap)
+        assert out.shape == (T, H) and not out.isnan().any() and not out.any()
+
+
 @pytest.mark.parametrize("awq,pair", [(False, False), (True, False), (False, True), (True, True)])
 def test_moe_decode_slots_on_the_burst_kernel(awq, pair, monkeypatch):
     """Expert layers wide enough to occupy the chip (>= 128 strips per slot) take the one-workgroup-

@@ -40,3 +40,31 @@ def test_expert_parallel_fused_moe_two_ranks_share_the_gpu(tmp_path):
         res = json.load(open(tmp_path / f"ep_rank{rank}.json"))
         assert res["rows"] == [2 + rank, 256], res
         assert res["max_err"] <= 2e-2 * res["scale"] + 2e-3, res
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_run_and_capture_at_world_size_one(tmp_path):
+    """The RCCL path every rank of an N > 1 run executes, on the one GPU: bench.py under
+    torch.distributed.run with backend nccl and MI355Q_FORCE_TP_PATH=1 issues the two all-reduces per layer
+    (vllm/model_executor/layers/linear.py:1763-1767) and the logits all-gather
+    (vllm/distributed/device_communicators/cuda_communicator.py:275-390) into the process group, captures them
+    into the decode graph, and must decode the tokens of the plain run; the 16 KiB all-reduce is timed eager and
+    captured."""
+    import json
+    common = ["bench.py", "--gpus", "1", "--model", "small", "--steps", "12", "--warmup", "2", "--skip-cpu", "--skip-bf16",
+              "--skip-shapes"]
+    env = dict(os.environ, PYTHONUNBUFFERED="1")
+    env.pop("MI355Q_FORCE_TP_PATH", None)
+    plain = subprocess.run([sys.executable] + common + ["--tokens-out", str(tmp_path / "plain.json")], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=400)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    env["MI355Q_FORCE_TP_PATH"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547"] + common + ["--tokens-out", str(tmp_path / "rccl.json")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["graph"] is True and line["graph_error"] is None, line
+    ar = line["allreduce_us_16k"]
+    assert ar["eager"] > 0 and ar["captured"] is not None and ar["captured"] > 0, ar
+    assert json.load(open(tmp_path / "rccl.json")) == json.load(open(tmp_path / "plain.json"))

@@ -182,6 +182,11 @@ class LlamaRunner:
         assert quant in ("gptq", "awq", "none")
         self.cfg, self.quant, self.dtype, self.device = cfg, quant, dtype, torch.device(device)
         self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
+        # MI355Q_FORCE_TP_PATH=1 with an initialised process group: issue the two all-reduces per layer and the
+        # logits all-gather even at world size 1, so that the RCCL calls (and their capture into the decode
+        # graph) execute on a one-GPU box exactly as a TP rank issues them
+        self.tp_collectives = tp_size > 1 or (os.environ.get("MI355Q_FORCE_TP_PATH") == "1"
+                                              and torch.distributed.is_available() and torch.distributed.is_initialized())
         self.G = group_size
         self.kv_cache_dtype = kv_cache_dtype
         self.fp8 = kv_cache_dtype.startswith("fp8")
@@ -278,7 +283,7 @@ class LlamaRunner:
         return torch.distributed.get_backend(self.tp_group) == "gloo"
 
     def _all_reduce(self, x):
-        if self.tp_size > 1:
+        if self.tp_collectives:
             if self._host_staged():
                 t = x.cpu()
                 torch.distributed.all_reduce(t, group=self.tp_group)
@@ -291,7 +296,7 @@ class LlamaRunner:
         """A row-parallel projection whose K-slice sums, residual add and the following RMSNorm can run
         as one kernel: the token range of the tiled kernel (or of the K-sliced rows kernel), whole
         projection on this rank."""
-        return (self.quant != "none" and self.tp_size == 1 and T <= ops.MM_MAX_TOKENS
+        return (self.quant != "none" and not self.tp_collectives and T <= ops.MM_MAX_TOKENS
                 and ops.w4a16_mm_add_rms_norm_supported(T, lin.w))
 
     def _layer(self, L, li, h, residual, positions, slot_mapping, attend, normed=False, next_norm=None):
@@ -393,7 +398,7 @@ class LlamaRunner:
             ops.fused_add_rms_norm(h, residual, self.norm, self.cfg.rms_eps)
         M = h.shape[0]
         logits = ops.linear_skinny(h, self.lm_head) if M <= 16 else torch.nn.functional.linear(h, self.lm_head)
-        if self.tp_size > 1:
+        if self.tp_collectives:
             src = logits.cpu() if self._host_staged() else logits
             parts = [torch.empty_like(src) for _ in range(self.tp_size)]
             torch.distributed.all_gather(parts, src, group=self.tp_group)

@@ -285,8 +285,11 @@ def fused_experts(x: torch.Tensor, w13: ops.PackedMoeW4, w2: ops.PackedMoeW4, to
         ys = ops.moe_w4a16_grouped_mm(act, w2, tile_expert, num_tiles)
         held = slot_pos >= 0
         y = ys.index_select(0, torch.clamp(slot_pos, min=0).long())        # back to slot order
-        if expert_map is not None:                                         # slots of experts held elsewhere add nothing
-            y = y * held.view(-1, 1).to(y.dtype)
+        if expert_map is not None:
+            # slots of experts held elsewhere add nothing.  Selected, not multiplied: their rows were gathered
+            # from row 0 of `ys`, which no tile wrote when this rank holds none of the selected experts, and
+            # uninitialised memory times zero may be NaN
+            y = torch.where(held.view(-1, 1), y, torch.zeros((), dtype=y.dtype, device=y.device))
     else:
         y = torch.zeros((slots, H), dtype=x.dtype, device=x.device)
         for e in ids.unique().tolist():

@@ -5,8 +5,8 @@ penalties applied (vllm/_custom_ops.py:309-357), greedy rows take the first arg-
 are temperature-scaled, top-k/top-p masked (ops/topk_topp_sampler.py:349-472: keep the k largest;
 then drop the lowest-probability tokens whose cumulative mass stays <= 1 - p, always keeping the
 top one) and sampled as argmax(softmax / Exp(1) noise) (:77-212).  Arg-max, the penalties and the
-random rows (temperature, both masks, softmax / noise arg-max: ops.sample_topk_topp) run in HIP; the
-torch formulation below serves CPU tensors.
+random rows (temperature, both masks, softmax / noise arg-max: ops.sample_topk_topp) run in HIP.  There
+is no second formulation: CPU tensors are refused by the op layer.
 """
 from dataclasses import dataclass, field
 
@@ -36,22 +36,6 @@ class SamplerOutput:
     sampled_token_ids: torch.Tensor   # int32 [B, 1]
 
 
-def apply_top_k_top_p(logits: torch.Tensor, k: torch.Tensor | None, p: torch.Tensor | None) -> torch.Tensor:
-    if k is None and p is None:
-        return logits
-    srt, idx = logits.sort(dim=-1, descending=False)
-    V = logits.shape[-1]
-    if k is not None:
-        kth = srt.gather(1, (V - k.to(torch.long).clamp(1, V)).unsqueeze(1))
-        srt.masked_fill_(srt < kth, float("-inf"))
-    if p is not None:
-        cum = srt.softmax(dim=-1).cumsum(dim=-1)
-        drop = cum <= (1 - p.unsqueeze(1))
-        drop[:, -1] = False
-        srt.masked_fill_(drop, float("-inf"))
-    return logits.scatter_(1, idx, srt)
-
-
 def exponential_noise(like: torch.Tensor, generators: dict[int, torch.Generator]) -> torch.Tensor:
     """Exp(1) draws, rows with their own generator overwritten from it (topk_topp_sampler.py:452-465)."""
     q = torch.empty_like(like, dtype=torch.float32)
@@ -60,10 +44,6 @@ def exponential_noise(like: torch.Tensor, generators: dict[int, torch.Generator]
     for i, g in generators.items():
         q[i].exponential_(generator=g)
     return q
-
-
-def random_sample(probs: torch.Tensor, generators: dict[int, torch.Generator]) -> torch.Tensor:
-    return probs.div_(exponential_noise(probs, generators)).argmax(dim=-1).view(-1)
 
 
 class Sampler(torch.nn.Module):
@@ -82,13 +62,8 @@ class Sampler(torch.nn.Module):
         temp = md.temperature
         if not md.all_random:
             temp = torch.where(temp < _SAMPLING_EPS, 1.0, temp)
-        if logits.is_cuda:
-            # one HIP kernel: temperature, both masks by radix selection, softmax / noise arg-max
-            sampled = ops.sample_topk_topp(logits.contiguous(), temp, md.top_k, md.top_p, exponential_noise(logits, md.generators))
-        else:
-            logits = logits.div_(temp.unsqueeze(1))
-            logits = apply_top_k_top_p(logits, md.top_k, md.top_p)
-            sampled = random_sample(logits.softmax(dim=-1, dtype=torch.float32), md.generators)
+        # one HIP kernel: temperature, both masks by radix selection, softmax / noise arg-max
+        sampled = ops.sample_topk_topp(logits.contiguous(), temp, md.top_k, md.top_p, exponential_noise(logits, md.generators))
         if greedy is not None:
             sampled = torch.where(md.temperature < _SAMPLING_EPS, greedy, sampled)
         return SamplerOutput(sampled.to(torch.int32).unsqueeze(-1))
