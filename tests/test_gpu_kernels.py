@@ -985,7 +985,8 @@ def test_w4a16_split_k_counters_are_left_clean():
     assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
 
 
-@pytest.mark.parametrize("H,KVH,D,bs,fp8", [(32, 8, 128, 16, False), (8, 2, 128, 32, True), (4, 4, 64, 16, False)])
+@pytest.mark.parametrize("H,KVH,D,bs,fp8", [(32, 8, 128, 16, False), (8, 2, 128, 32, True), (4, 4, 64, 16, False),
+                                          (8, 1, 128, 16, False), (16, 1, 128, 64, True), (6, 2, 64, 32, False)])
 def test_decode_attention_fused_equals_unfused(H, KVH, D, bs, fp8):
     """One launch (RoPE + cache write + attention) == rotary_embedding, reshape_and_cache,
     paged_attention_rocm back to back: outputs and cache contents bit for bit."""

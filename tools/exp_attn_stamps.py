@@ -18,9 +18,9 @@ L.mi355q_debug_attention_stamps(st.data_ptr())
 r._decode_body()          # the last layer's launch overwrites: that is the one kept
 torch.cuda.synchronize()
 L.mi355q_debug_attention_stamps(None)
-t = st[:8, [0, 6, 7, 1, 2, 3, 4, 5]].cpu().double()
+t = st[:8, [0, 6, 8, 7, 1, 2, 3, 4, 5]].cpu().double()
 t = (t - t[:, 0].min()) / 100.0
-print("per kv-head workgroup, us after first entry: entry | seq_len known | q roped | patched | QK | softmax | PV | stored")
+print("per kv-head workgroup, us after first entry: entry | seq_len known | requests issued | q roped | patched | QK | softmax | PV | stored")
 for row in t.tolist(): print(" ".join(f"{v:6.2f}" for v in row))
 
 # same launch repeated back to back: instruction cache and K/V lines warm
@@ -42,7 +42,7 @@ L.mi355q_debug_attention_stamps(st.data_ptr())
 go()
 torch.cuda.synchronize()
 L.mi355q_debug_attention_stamps(None)
-t = st[:8, [0, 6, 7, 1, 2, 3, 4, 5]].cpu().double()
+t = st[:8, [0, 6, 8, 7, 1, 2, 3, 4, 5]].cpu().double()
 t = (t - t[:, 0].min()) / 100.0
 print("repeated launch (warm):")
 for row in t.tolist()[:3]: print(" ".join(f"{v:6.2f}" for v in row))

@@ -45,6 +45,7 @@ struct PAParams {
   int varlen;          // 0: decode rows only, 1: every row, several query tokens per block
   int qblocks_per_seq; // varlen: ceil(max_query_len / QB)
   int gp;              // columns per query token (power of two >= group size)
+  int g;               // query heads per kv head
   int bs_shift;        // log2(bs) when the block size is a power of two, else -1
   // fused decode step (FUSED kernels): q points into the qkv projection output, the new
   // token's k/v sit k_off / v_off elements after the row start; NeoX RoPE over the whole head
@@ -113,7 +114,7 @@ __device__ inline void rope8(u32x4& x, u32x4& y, const u32x4 c, const u32x4 s) {
 
 #define PA_STAMP(i)                                                                              \
   if (p.stamps && threadIdx.x == 0)                                                              \
-    p.stamps[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * 10 + (i)] = ((i) >= 8 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime())
+    p.stamps[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * 10 + (i)] = ((i) >= 9 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime())
 
 static unsigned long long* g_pa_stamps = nullptr;
 
@@ -710,6 +711,519 @@ __global__ __launch_bounds__(HEAD) void paged_attention_reduce_kernel(const PAPa
 }
 
 // ---------------------------------------------------------------------------
+// The decode step's attention launch: RoPE (NeoX, whole head) on the query heads and on the new key, the append
+// of the new key / value to the paged cache, and the attention of ONE new token per sequence, as one kernel
+// (the sequence rotary_embedding -> reshape_and_cache -> paged_attention of
+// vllm/v1/attention/backends/rocm_attn.py:367-517, csrc/rocm/attention.cu:317-914 for the arithmetic).
+//
+// Same decomposition and the same fp32 operations in the same order as paged_attention_kernel above -- one
+// workgroup of 4 waves per (sequence, 256-token partition, kv head), wave w owns tokens 64 w .. 64 w + 63,
+// probabilities normalised inside the partition and rounded to the activation dtype -- so its outputs equal that
+// kernel's bit for bit.  What differs is the order in which things are asked for, because at decode sizes the
+// launch is nothing but a chain of memory round trips:
+//   * everything that only the STEP defines (sequence length, position, this wave's block-table entries) is read
+//     through the scalar cache: wave-uniform, counted apart from the vector loads, and back long before the
+//     operands the previous launch has just written (q, new k, new v), which are requested in the same breath;
+//   * the K / V tiles and the position's cos / sin row are requested the moment the scalar data is back -- they
+//     do not wait for q -- so the two round trips of a dependent chain overlap into one;
+//   * the new key is fetched in MFMA-fragment order like q, rotated in registers by every wave and patched into
+//     the K fragments of the tile that holds the newest position; the new value likewise: no LDS stage, no
+//     barrier in front of the first product.  The wave whose tile holds the new position writes both to the cache;
+//   * integer divisions are gone from the prelude (block size and group padding are powers of two here; other
+//     block sizes take paged_attention_kernel's fused form);
+//   * the two wave-level reductions of the softmax use v_permlane16_swap / v_permlane32_swap instead of LDS
+//     permutes, and only the columns of real query heads travel through LDS in the cross-wave sum.
+// Columns of the 16-wide MFMA tile beyond the group's heads repeat the last head: finite everywhere, never stored.
+// ---------------------------------------------------------------------------
+typedef const int32_t __attribute__((address_space(4)))* pa_ci32p;   // read through the scalar cache
+typedef const int64_t __attribute__((address_space(4)))* pa_ci64p;
+typedef const float __attribute__((address_space(4)))* pa_cf32p;
+typedef __attribute__((ext_vector_type(2))) unsigned pa_u2;
+
+// max / sum over the four lanes (kq = 0..3) that share a column
+__device__ inline float quad_rows_max(float v) {
+  pa_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// the pairing of __shfl_xor(v, 16) then (v, 32): (own + partner) each time, so the sum is the same bits
+__device__ inline float quad_rows_sum(float v) {
+  const int kq = (threadIdx.x & 63) >> 4;
+  pa_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  // r[0]: rows (0,0,2,2), r[1]: rows (1,1,3,3); own + partner
+  v = (kq & 1) ? __uint_as_float(r[1]) + __uint_as_float(r[0]) : __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return (kq & 2) ? __uint_as_float(r[1]) + __uint_as_float(r[0]) : __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <typename DT, int HEAD, bool KVFP8>
+__global__ __launch_bounds__(256, 2) void decode_step_kernel(const PAParams p) {
+  constexpr int DS = HEAD / 32, DTILES = HEAD / 16, KR = KVFP8 ? DS / 2 : DS;
+  constexpr int OPAD = HEAD + 4;   // floats per column of the cross-wave sum: columns land on different banks
+  __shared__ float s_max[4][16];
+  __shared__ float s_sum[4][16];
+  __shared__ __attribute__((aligned(16))) float s_out[4][16][OPAD];
+  __shared__ int s_last;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kq = lane >> 4, col = lane & 15;
+  const int seq = blockIdx.x, part = blockIdx.y, kvh = blockIdx.z;
+  const int g = p.g, gp = p.gp, bsh = p.bs_shift, bs = p.bs;
+  PA_STAMP(0);
+
+  // ---- what the step defines: scalar loads ---------------------------------------------------------------
+  const int seq_len = ((pa_ci32p)p.seq_lens)[seq];
+  const int64_t pos = ((pa_ci64p)p.positions)[seq];
+  const float kscale = KVFP8 ? *(pa_cf32p)p.k_scale : 1.0f, vscale = KVFP8 ? *(pa_cf32p)p.v_scale : 1.0f;
+  const int p0 = part * MI355Q_PA_PARTITION;
+  const int wave_t0 = p0 + wave * 64;
+  pa_ci32p table = (pa_ci32p)p.block_tables + (size_t)seq * p.max_blocks;
+  int ent[4];
+#pragma unroll
+  for (int T = 0; T < 4; T++) ent[T] = table[min((wave_t0 + T * 16) >> bsh, p.max_blocks - 1)];
+
+  // ---- what the previous launch wrote: q, the new key (both in fragment order), the new value ----------------
+  // fragment ds of a lane covers head dims d0(ds) .. d0(ds) + 7
+  //   16-bit cache: d0 = 32 ds + 8 kq;   fp8 cache: d0 = 16 (4 (ds / 2) + kq) + 8 (ds & 1)
+  const uint16_t* rowp = p.q + (size_t)seq * p.q_stride;
+  const int hq = min(col & (gp - 1), g - 1);
+  const uint16_t* qp = rowp + (size_t)(kvh * g + hq) * HEAD;
+  const uint16_t* kp = rowp + p.k_off + kvh * HEAD;
+  const uint16_t* vp = rowp + p.v_off + kvh * HEAD + col;
+  u32x4 qf[DS], kf[DS];
+  uint16_t vn[DTILES];
+#pragma unroll
+  for (int ds = 0; ds < DS; ds++) {
+    const int d0 = KVFP8 ? 16 * (4 * (ds >> 1) + kq) + 8 * (ds & 1) : 32 * ds + 8 * kq;
+    qf[ds] = *reinterpret_cast<const u32x4*>(qp + d0);
+    kf[ds] = *reinterpret_cast<const u32x4*>(kp + d0);
+  }
+#pragma unroll
+  for (int dt = 0; dt < DTILES; dt++) vn[dt] = vp[dt * 16];
+  __builtin_amdgcn_sched_barrier(0);
+
+  if (p0 >= seq_len) {
+    // a partition past the context.  The operands above are named here so that their requests stay in front of
+    // this branch for the workgroups that go on (a load whose result only the other side needs is moved there).
+    uint32_t t0 = vn[0], t1 = vn[DTILES - 1];
+    asm volatile("" ::"v"(qf[0][0]), "v"(qf[DS - 1][3]), "v"(kf[0][0]), "v"(kf[DS - 1][3]), "v"(t0), "v"(t1));
+    asm volatile("" ::"s"(ent[0]), "s"(ent[1]), "s"(ent[2]), "s"(ent[3]), "s"(pos), "s"(kscale), "s"(vscale));
+    return;
+  }
+  PA_STAMP(6);
+
+  // ---- second group: cos / sin of the position, K and V tiles ----------------------------------------------
+  u32x4 cfrag[DS / 2], sfrag[DS / 2];
+  {
+    const uint16_t* cs = p.cos_sin + (size_t)pos * HEAD;
+#pragma unroll
+    for (int ds = 0; ds < DS / 2; ds++) {
+      const int d0 = KVFP8 ? 16 * (4 * (ds >> 1) + kq) + 8 * (ds & 1) : 32 * ds + 8 * kq;
+      cfrag[ds] = *reinterpret_cast<const u32x4*>(cs + d0);
+      sfrag[ds] = *reinterpret_cast<const u32x4*>(cs + HEAD / 2 + d0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);   // requests in the order of use: vector loads return in issue order
+  // A tile past the context reads cache block 0 (always mapped) and is skipped or masked below.
+  bool tile_on[4];
+  u32x4 kreg[4][KR];
+  u32x2 vreg[4][DTILES];
+#pragma unroll
+  for (int T = 0; T < 4; T++) tile_on[T] = wave_t0 + T * 16 < seq_len;
+  // Addresses: one buffer descriptor per tile (block, kv head, the tile's first row; wave-uniform, in scalar
+  // registers) plus ONE 32-bit lane offset shared by all of the lane's requests; the fragment index is a scalar
+  // offset.  A tile past the context gets a descriptor of size zero: its loads stay in the instruction stream
+  // (no branch, so every later wait counts exactly) but every lane is out of range, which returns zeros and sends
+  // nothing to the cache -- the L1 path of the CU moves 64 bytes per clock, and at a 170-token context a third of
+  // the sixteen tiles would be wasted on it.
+  constexpr int EBY = KVFP8 ? 1 : 2;                                   // bytes per cache element
+  __amdgpu_buffer_rsrc_t kdesc[4], vdesc[4];
+#pragma unroll
+  for (int T = 0; T < 4; T++) {
+    const int blk = tile_on[T] ? ent[T] : 0;
+    const int row0 = (wave_t0 + T * 16) & (bs - 1);                    // the tile's first token row in its block
+    const size_t base = ((size_t)blk * p.kv_block_stride + (size_t)kvh * p.kv_head_stride) * EBY;
+    const int span = tile_on[T] ? 0x7fffffff : 0;
+    kdesc[T] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.kc)) + base + (size_t)row0 * 16,
+                                                 0, span, 0x00020000);
+    vdesc[T] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.vc)) + base + (size_t)row0 * EBY,
+                                                 0, span, 0x00020000);
+  }
+  const int koff = (kq * bs + col) * 16;                  // K: 16-byte groups [head dims / x][row]
+  const int voff = (col * bs + 4 * kq) * EBY;             // V: [head dim][row]
+#pragma unroll
+  for (int T = 0; T < 4; T++) {
+#pragma unroll
+    for (int r = 0; r < KR; r++)
+      kreg[T][r] = __builtin_amdgcn_raw_buffer_load_b128(kdesc[T], koff, r * 64 * bs, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // The V tiles are requested further down, in two halves between the arithmetic: the CU's L1 path takes in
+  // 64 bytes per clock and a wave cannot run ahead of its own requests, so a wave that asks for everything at
+  // once stands at the last request until the path has drained -- with the arithmetic on q and K still to do.
+  auto request_v = [&](int T) {
+#pragma unroll
+    for (int dt = 0; dt < DTILES; dt++) {
+      if constexpr (!KVFP8) {
+        vreg[T][dt] = __builtin_amdgcn_raw_buffer_load_b64(vdesc[T], voff, dt * 16 * bs * EBY, 0);
+      } else {
+        vreg[T][dt][0] = __builtin_amdgcn_raw_buffer_load_b32(vdesc[T], voff, dt * 16 * bs * EBY, 0);
+        vreg[T][dt][1] = 0u;
+      }
+    }
+  };
+  PA_STAMP(8);
+
+  // ---- RoPE on q and on the new key: the partner d + HEAD / 2 of every element is fragment ds + DS / 2 ----------
+#pragma unroll
+  for (int ds = 0; ds < DS / 2; ds++) {
+    rope8<DT>(qf[ds], qf[ds + DS / 2], cfrag[ds], sfrag[ds]);
+    rope8<DT>(kf[ds], kf[ds + DS / 2], cfrag[ds], sfrag[ds]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  request_v(0);
+  request_v(1);
+  __builtin_amdgcn_sched_barrier(0);
+  PA_STAMP(7);
+
+  // ---- the new token: into the cache, and into the fragments of the tile that holds it ---------------------------
+  // (the key here, in front of the first product; the value further down, in front of the second: its patch
+  // needs the V tile, the youngest of the requests above)
+  const int tnew = seq_len - 1;
+  const int tl = tnew - wave_t0;          // wave-uniform
+  const bool owns_new = tl >= 0 && tl < 64;
+  const int Tn = tl >> 4, cn = tl & 15;
+  uint32_t vnew[DTILES];                  // the value's cache form, one element per head-dim tile
+#pragma unroll
+  for (int dt = 0; dt < DTILES; dt++) {
+    if constexpr (!KVFP8) vnew[dt] = vn[dt];
+    else vnew[dt] = f32_to_fp8(DT::to_f32(vn[dt]) / vscale);
+  }
+  if (owns_new) {
+    u32x4 knew[KR];                       // the key's cache form
+    if constexpr (!KVFP8) {
+#pragma unroll
+      for (int ds = 0; ds < DS; ds++) knew[ds] = kf[ds];
+    } else {
+      auto enc4 = [&](uint32_t lo, uint32_t hi) {   // four 16-bit values -> four e4m3 bytes of value / k_scale
+        const float a = DT::to_f32((uint16_t)(lo & 0xffff)) / kscale, b = DT::to_f32((uint16_t)(lo >> 16)) / kscale;
+        const float c = DT::to_f32((uint16_t)(hi & 0xffff)) / kscale, d = DT::to_f32((uint16_t)(hi >> 16)) / kscale;
+        return (uint32_t)f32_to_fp8(a) | ((uint32_t)f32_to_fp8(b) << 8) | ((uint32_t)f32_to_fp8(c) << 16) |
+               ((uint32_t)f32_to_fp8(d) << 24);
+      };
+#pragma unroll
+      for (int sp = 0; sp < DS / 2; sp++)
+        knew[sp] = u32x4{enc4(kf[2 * sp][0], kf[2 * sp][1]), enc4(kf[2 * sp][2], kf[2 * sp][3]),
+                         enc4(kf[2 * sp + 1][0], kf[2 * sp + 1][1]), enc4(kf[2 * sp + 1][2], kf[2 * sp + 1][3])};
+    }
+    // cache append: the block is this wave's entry of the tile
+    const int blk = Tn == 0 ? ent[0] : (Tn == 1 ? ent[1] : (Tn == 2 ? ent[2] : ent[3]));
+    const int off = tnew & (bs - 1);
+    const size_t base = (size_t)blk * p.kv_block_stride + (size_t)kvh * p.kv_head_stride;
+    if (col == 0) {     // four lanes hold the whole key, 16 bytes (one x-group of the K layout) per fragment
+      if constexpr (!KVFP8) {
+        uint16_t* kb = reinterpret_cast<uint16_t*>(const_cast<void*>(p.kc)) + base;
+#pragma unroll
+        for (int ds = 0; ds < DS; ds++) *reinterpret_cast<u32x4*>(kb + ((size_t)(ds * 4 + kq) * bs + off) * 8) = knew[ds];
+      } else {
+        uint8_t* kb = reinterpret_cast<uint8_t*>(const_cast<void*>(p.kc)) + base;
+#pragma unroll
+        for (int sp = 0; sp < DS / 2; sp++) *reinterpret_cast<u32x4*>(kb + ((size_t)(sp * 4 + kq) * bs + off) * 16) = knew[sp];
+      }
+    }
+    if (kq == 0) {      // sixteen lanes hold the value, head dims 16 dt + col
+      if constexpr (!KVFP8) {
+        uint16_t* vb = reinterpret_cast<uint16_t*>(const_cast<void*>(p.vc)) + base;
+#pragma unroll
+        for (int dt = 0; dt < DTILES; dt++) vb[(size_t)(dt * 16 + col) * bs + off] = (uint16_t)vnew[dt];
+      } else {
+        uint8_t* vb = reinterpret_cast<uint8_t*>(const_cast<void*>(p.vc)) + base;
+#pragma unroll
+        for (int dt = 0; dt < DTILES; dt++) vb[(size_t)(dt * 16 + col) * bs + off] = (uint8_t)vnew[dt];
+      }
+    }
+    // this step's reads of that slot are replaced in registers (nobody waits for the stores)
+    const bool krow = col == cn;                 // the lane's K row is the new token
+#pragma unroll
+    for (int T = 0; T < 4; T++) {
+      if (T == Tn) {
+#pragma unroll
+        for (int r = 0; r < KR; r++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) kreg[T][r][e] = krow ? knew[r][e] : kreg[T][r][e];
+      }
+    }
+  }
+
+  PA_STAMP(1);
+  // ---- S^T = K Q^T ---------------------------------------------------------------------------------------
+  f32x4 st[4];
+  auto qk_tile = [&](int T) {
+    st[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tile_on[T]) {
+      if constexpr (!KVFP8) {
+#pragma unroll
+        for (int ds = 0; ds < DS; ds++) st[T] = mfma16<DT>(kreg[T][ds], qf[ds], st[T]);
+      } else {
+#pragma unroll
+        for (int sp = 0; sp < DS / 2; sp++) {
+          const u32x4 raw = kreg[T][sp];
+          const u32x2 a0 = fp8x4_to_h16<DT>(raw[0]), a1 = fp8x4_to_h16<DT>(raw[1]);
+          const u32x2 b0 = fp8x4_to_h16<DT>(raw[2]), b1 = fp8x4_to_h16<DT>(raw[3]);
+          st[T] = mfma16<DT>(u32x4{a0[0], a0[1], a1[0], a1[1]}, qf[2 * sp], st[T]);
+          st[T] = mfma16<DT>(u32x4{b0[0], b0[1], b1[0], b1[1]}, qf[2 * sp + 1], st[T]);
+        }
+      }
+    }
+  };
+  qk_tile(0);
+  qk_tile(1);
+  __builtin_amdgcn_sched_barrier(0);
+  request_v(2);
+  request_v(3);
+  __builtin_amdgcn_sched_barrier(0);
+  qk_tile(2);
+  qk_tile(3);
+  PA_STAMP(2);
+
+  // ---- logits, partition max / sum per column (the arithmetic of paged_attention_kernel) ----------------------
+  const float scale = p.scale * kscale;
+  float mw = -INFINITY;
+#pragma unroll
+  for (int T = 0; T < 4; T++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int tok = wave_t0 + T * 16 + 4 * kq + r;
+      float v = st[T][r] * scale;
+      v = tok < seq_len ? v : -INFINITY;
+      st[T][r] = v;
+      mw = fmaxf(mw, v);
+    }
+  mw = quad_rows_max(mw);
+  const float mwref = mw == -INFINITY ? 0.f : mw;
+  float sw = 0.f;
+#pragma unroll
+  for (int T = 0; T < 4; T++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float e = __expf(st[T][r] - mwref);
+      st[T][r] = e;
+      sw += e;
+    }
+  sw = quad_rows_sum(sw);
+  if (kq == 0) {
+    s_max[wave][col] = mw;
+    s_sum[wave][col] = sw;
+  }
+  __syncthreads();
+  float m4[4], s4[4];
+#pragma unroll
+  for (int w2 = 0; w2 < 4; w2++) {
+    m4[w2] = s_max[w2][col];
+    s4[w2] = s_sum[w2][col];
+  }
+  float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+  const float mref = mx == -INFINITY ? 0.f : mx;
+  float sum = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < 4; w2++)   // a wave past the context published (-inf, 0): its term is exp(-inf) * 0 = 0
+    sum += s4[w2] * __expf(m4[w2] - mref);
+  const float inv = (mw == -INFINITY ? 0.f : __expf(mwref - mref)) / (sum + 1e-6f);
+  PA_STAMP(3);
+
+  // the new value into the V fragments: bit-field inserts, the position inside the tile is a run-time value
+  if (owns_new) {
+    const bool vrow = kq == (cn >> 2);           // the lane's four V tokens hold it
+    constexpr int EB = KVFP8 ? 8 : 16;           // bits per cache element
+    const int j = cn & 3;
+    const int sh = (EB * j) & 31;
+    const uint32_t m = (KVFP8 ? 0xffu : 0xffffu) << sh;
+    const uint32_t m0 = (vrow && (KVFP8 || j < 2)) ? m : 0u;     // element j lives in word 0 ...
+    const uint32_t m1 = (vrow && !KVFP8 && j >= 2) ? m : 0u;     // ... or word 1 of the lane's 64 bits
+#pragma unroll
+    for (int T = 0; T < 4; T++) {
+      if (T == Tn) {
+#pragma unroll
+        for (int dt = 0; dt < DTILES; dt++) {
+          const uint32_t val = vnew[dt] << sh;
+          vreg[T][dt][0] = (vreg[T][dt][0] & ~m0) | (val & m0);
+          if constexpr (!KVFP8) vreg[T][dt][1] = (vreg[T][dt][1] & ~m1) | (val & m1);
+        }
+      }
+    }
+  }
+
+  // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------
+  f32x4 o[DTILES];
+#pragma unroll
+  for (int dt = 0; dt < DTILES; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s2 = 0; s2 < 2; s2++) {
+    const int Te = 2 * s2, To = 2 * s2 + 1;
+    if (tile_on[Te]) {
+      u32x4 pf;
+      pf[0] = pack2<DT>(st[Te][0] * inv, st[Te][1] * inv);
+      pf[1] = pack2<DT>(st[Te][2] * inv, st[Te][3] * inv);
+      pf[2] = pack2<DT>(st[To][0] * inv, st[To][1] * inv);
+      pf[3] = pack2<DT>(st[To][2] * inv, st[To][3] * inv);
+      // tokens at or past seq_len hold unwritten cache memory: force their V to zero
+      const int te0 = wave_t0 + Te * 16 + 4 * kq, to0 = wave_t0 + To * 16 + 4 * kq;
+      const int ne = min(max(seq_len - te0, 0), 4), no = min(max(seq_len - to0, 0), 4);
+      const uint32_t me0 = ne >= 2 ? 0xffffffffu : (ne == 1 ? 0x0000ffffu : 0u);
+      const uint32_t me1 = ne >= 4 ? 0xffffffffu : (ne == 3 ? 0x0000ffffu : 0u);
+      const uint32_t mo0 = no >= 2 ? 0xffffffffu : (no == 1 ? 0x0000ffffu : 0u);
+      const uint32_t mo1 = no >= 4 ? 0xffffffffu : (no == 3 ? 0x0000ffffu : 0u);
+      const bool odd_ok = tile_on[To];
+      if (wave_t0 + (To + 1) * 16 <= seq_len) {   // wave-uniform: every token of the pair is cached, no mask needed
+#pragma unroll
+        for (int dt = 0; dt < DTILES; dt++) {
+          u32x2 ve, vo;
+          if constexpr (!KVFP8) {
+            ve = vreg[Te][dt];
+            vo = vreg[To][dt];
+          } else {
+            ve = fp8x4_to_h16<DT>(vreg[Te][dt][0]);
+            vo = fp8x4_to_h16<DT>(vreg[To][dt][0]);
+          }
+          o[dt] = mfma16<DT>(u32x4{ve[0], ve[1], vo[0], vo[1]}, pf, o[dt]);
+        }
+      } else {
+#pragma unroll
+        for (int dt = 0; dt < DTILES; dt++) {
+          u32x2 ve, vo = u32x2{0u, 0u};
+          if constexpr (!KVFP8) {
+            ve = vreg[Te][dt];
+            if (odd_ok) vo = vreg[To][dt];
+          } else {
+            ve = fp8x4_to_h16<DT>(vreg[Te][dt][0]);
+            if (odd_ok) vo = fp8x4_to_h16<DT>(vreg[To][dt][0]);
+          }
+          const u32x4 vf = u32x4{ve[0] & me0, ve[1] & me1, vo[0] & mo0, vo[1] & mo1};
+          o[dt] = mfma16<DT>(vf, pf, o[dt]);
+        }
+      }
+    }
+  }
+  PA_STAMP(4);
+
+  // ---- cross-wave sum of O (columns of real heads only), store ---------------------------------------------------
+  if (col < g) {
+#pragma unroll
+    for (int dt = 0; dt < DTILES; dt++)
+      *reinterpret_cast<f32x4*>(&s_out[wave][col][dt * 16 + 4 * kq]) = o[dt] * vscale;
+  }
+  __syncthreads();
+
+  const int nactive = (seq_len + MI355Q_PA_PARTITION - 1) / MI355Q_PA_PARTITION;
+  const bool single = p.max_parts == 1 || (p.inline_reduce && nactive == 1);
+  typedef unsigned long long u64;
+  for (int idx = threadIdx.x; idx < g * (HEAD / 8); idx += 256) {   // 8 consecutive head dims per thread
+    const int c = idx / (HEAD / 8), d = (idx - c * (HEAD / 8)) * 8;
+    f32x4 lo4 = f32x4{0.f, 0.f, 0.f, 0.f}, hi4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w2 = 0; w2 < 4; w2++) {
+      lo4 += *reinterpret_cast<const f32x4*>(&s_out[w2][c][d]);
+      hi4 += *reinterpret_cast<const f32x4*>(&s_out[w2][c][d + 4]);
+    }
+    u32x4 o8;
+    o8[0] = pack2<DT>(lo4[0], lo4[1]); o8[1] = pack2<DT>(lo4[2], lo4[3]);
+    o8[2] = pack2<DT>(hi4[0], hi4[1]); o8[3] = pack2<DT>(hi4[2], hi4[3]);
+    const int h = kvh * g + c;
+    if (single) {
+      *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.out) + ((size_t)seq * p.num_heads + h) * HEAD + d) = o8;
+    } else {
+      uint16_t* dst = reinterpret_cast<uint16_t*>(p.tmp_out) + (((size_t)seq * p.num_heads + h) * p.max_parts + part) * HEAD + d;
+      if (p.inline_reduce) {   // write-through: another workgroup reads these in this launch
+        __hip_atomic_store(reinterpret_cast<u64*>(dst), (u64)o8[0] | ((u64)o8[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<u64*>(dst) + 1, (u64)o8[2] | ((u64)o8[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        *reinterpret_cast<u32x4*>(dst) = o8;
+      }
+    }
+  }
+  PA_STAMP(5);
+  if (single) return;
+  if (wave == 0 && kq == 0 && col < g) {
+    const size_t o2 = ((size_t)seq * p.num_heads + (kvh * g + col)) * p.max_parts + part;
+    if (p.inline_reduce) {
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(p.exp_sums + o2), __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(p.max_logits + o2), __float_as_uint(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      p.exp_sums[o2] = sum;
+      p.max_logits[o2] = mx;
+    }
+  }
+  if (!p.inline_reduce) return;
+
+  // ---- merge of the partitions by the last workgroup to arrive (the hand-off of paged_attention_kernel) ----------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int* cnt = g_pa_cnt + (size_t)p.cnt_bank * PA_BANK + (size_t)blockIdx.x * gridDim.z + blockIdx.z;
+    const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == nactive - 1;
+    if (last) {
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  for (int idx = threadIdx.x; idx < g * (HEAD / 8); idx += 256) {
+    const int c = idx / (HEAD / 8), d = (idx - c * (HEAD / 8)) * 8;
+    const int h = kvh * g + c;
+    const int nparts = nactive;
+    const size_t base = ((size_t)seq * p.num_heads + h) * p.max_parts;
+    constexpr int MB = 8;   // partitions per round trip (indices past the last repeat it and are skipped in the sums)
+    auto ld32 = [](const float* q) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+    float gmax = -INFINITY;
+    for (int i0 = 0; i0 < nparts; i0 += MB) {
+      float m8[MB];
+#pragma unroll
+      for (int u = 0; u < MB; u++) m8[u] = ld32(p.max_logits + base + min(i0 + u, nparts - 1));
+#pragma unroll
+      for (int u = 0; u < MB; u++) gmax = fmaxf(gmax, m8[u]);
+    }
+    float wsum = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint16_t* tmp = reinterpret_cast<const uint16_t*>(p.tmp_out) + base * HEAD + d;
+    for (int i0 = 0; i0 < nparts; i0 += MB) {
+      float es8[MB], ml8[MB];
+      u64 a8[MB], b8[MB];
+#pragma unroll
+      for (int u = 0; u < MB; u++) {
+        const int i = min(i0 + u, nparts - 1);
+        es8[u] = ld32(p.exp_sums + base + i);
+        ml8[u] = ld32(p.max_logits + base + i);
+        a8[u] = __hip_atomic_load(reinterpret_cast<const u64*>(tmp + (size_t)i * HEAD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b8[u] = __hip_atomic_load(reinterpret_cast<const u64*>(tmp + (size_t)i * HEAD) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < MB; u++) {
+        if (i0 + u < nparts) {   // in partition order, as the stand-alone merge kernel sums them
+          const float w = es8[u] * __expf(ml8[u] - gmax);
+          wsum += w;
+          const uint32_t wd[4] = {(uint32_t)a8[u], (uint32_t)(a8[u] >> 32), (uint32_t)b8[u], (uint32_t)(b8[u] >> 32)};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            acc[2 * e] += DT::to_f32((uint16_t)(wd[e] & 0xffff)) * w;
+            acc[2 * e + 1] += DT::to_f32((uint16_t)(wd[e] >> 16)) * w;
+          }
+        }
+      }
+    }
+    const float den = wsum + 1e-6f;
+    u32x4 o8;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o8[e] = pack2<DT>(acc[2 * e] / den, acc[2 * e + 1] / den);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.out) + ((size_t)seq * p.num_heads + h) * HEAD + d) = o8;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Prompt rows over a 16-bit cache, long queries: one workgroup = 16 column tiles (256 / gp query tokens x gp
 // heads: 64 tokens at four query heads per kv head) of one sequence x one kv head, walking the visible context
 // in tiles of 64 tokens with a running softmax (no partitions, no scratch, no merge).  The kernel above gives every 16 MFMA columns (16 / gp query
@@ -1167,8 +1681,18 @@ static int launch_pa(const PAParams& p_in, int head_size, int kv_fp8, int qblock
     if (bank >= 0) { p.cnt_bank = bank; p.inline_reduce = 1; }
   }
   dim3 grid(qblocks, p.max_parts, p.num_kv_heads), block(256);
+  // the decode step: its own kernel (power-of-two block sizes; MI355Q_DECODE_STEP_GENERIC=1 keeps the fused form
+  // of the general kernel, for comparisons)
+  const bool step_kernel = fused && p.bs_shift >= 0 && !env_flag("MI355Q_DECODE_STEP_GENERIC");
 #define MI355Q_PA(H, F8, FU) hipLaunchKernelGGL((paged_attention_kernel<DT, H, F8, FU>), grid, block, 0, stream, p)
-  if (fused) {
+  if (step_kernel) {
+    if (head_size == 128) {
+      if (kv_fp8) hipLaunchKernelGGL((decode_step_kernel<DT, 128, true>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((decode_step_kernel<DT, 128, false>), grid, block, 0, stream, p);
+    } else {
+      hipLaunchKernelGGL((decode_step_kernel<DT, 64, false>), grid, block, 0, stream, p);
+    }
+  } else if (fused) {
     if (head_size == 128) { if (kv_fp8) MI355Q_PA(128, true, true); else MI355Q_PA(128, false, true); }
     else MI355Q_PA(64, false, true);
   } else if (head_size == 128) { if (kv_fp8) MI355Q_PA(128, true, false); else MI355Q_PA(128, false, false); }
@@ -1205,6 +1729,7 @@ static int pa_common(PAParams& p, int head_size, int block_size, int max_seq_len
   int gp = 1;
   while (gp < g) gp <<= 1;
   p.gp = gp;
+  p.g = g;
   p.bs_shift = (block_size & (block_size - 1)) == 0 ? __builtin_ctz((unsigned)block_size) : -1;
   return 0;
 }
