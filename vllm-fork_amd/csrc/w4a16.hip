@@ -746,12 +746,12 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
   uint16_t* zc_l = sc_l + (size_t)groups * SW;                                 // [groups][SW] (HAS_ZC)
   uint16_t* act = zc_l + (HAS_ZC ? (size_t)groups * SW : 0);                   // [rows_pp][astride]
 
-  const u32x4* wstrip = p.wp + (size_t)strip * p.chunks * NS * 64 + lane;
+  const u32x4* wstrip = p.wp + (size_t)strip * p.chunks * NS * 64;   // wave-uniform: the base of a buffer descriptor
   const uint16_t* scales_e = p.scales;
   const uint16_t* zc_e = p.zc;
   int xrow0 = row0;
   if (p.expert_ids) {
-    const int e = p.expert_ids[row0];
+    const int e = __builtin_amdgcn_readfirstlane(p.expert_ids[row0]);
     if (e < 0) {   // expert held by another rank: the slot contributes nothing
       const int ncols = p.epi_silu ? SW / 2 : SW;
       uint16_t* o = p.out + (size_t)row0 * (p.epi_silu ? p.N >> 1 : p.N) + (size_t)strip * ncols;
@@ -804,11 +804,22 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
     else z_reg[i] = 0u;
   }
 
+  // The strip's weights are read through a buffer descriptor that spans exactly the strip: lane offset in a
+  // vector register, plane offset in a scalar one, non-temporal.  A request past the strip returns zeros and
+  // moves no data, which lets the refill of the ring below be UNCONDITIONAL: a refill under `if (more bursts)`
+  // makes every wait behind it count as if the refill had not been issued, i.e. the next chunk's first plane
+  // then waits for one plane of the refill as well -- a whole memory round trip in the middle of the stream.
   u32x4 w[CPW][NS];
-  auto issue_chunk = [&](int burst, int i) {
-    const size_t c = (size_t)(cfirst + burst * CPW + i);
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int cfirst_s = wave_s * cpw_total;
+  const __amdgpu_buffer_rsrc_t wdesc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(wstrip), 0, p.chunks * NS * 1024, 0x00020000);
+  const int wlane = lane * 16;
+  constexpr int W_NT = 2;                  // cache policy bits of the load: non-temporal
+  auto issue_chunk = [&](int burst, int i, int voff) {
+    const int c = cfirst_s + burst * CPW + i;
 #pragma unroll
-    for (int pl = 0; pl < NS; pl++) w[i][pl] = __builtin_nontemporal_load(wstrip + (c * NS + pl) * 64);
+    for (int pl = 0; pl < NS; pl++) w[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wdesc, voff, (c * NS + pl) * 1024, W_NT);
   };
   // Metered start.  Requesting the whole ring (up to 112 KiB per CU, 28 MB over the chip) the moment the
   // kernel starts floods the memory system's queues: every later request of the chip -- the prologue
@@ -845,7 +856,7 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
   constexpr int FP = FPQ < RING ? FPQ : RING;
   auto issue_plane = [&](int f) {   // plane f of the first ring fill
     const int i = f / NS, pl = f % NS;
-    w[i][pl] = __builtin_nontemporal_load(wstrip + ((size_t)(cfirst + i) * NS + pl) * 64);
+    w[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wdesc, wlane, ((cfirst_s + i) * NS + pl) * 1024, W_NT);
   };
 #pragma unroll
   for (int f = 0; f < FP; f++) issue_plane(f);
@@ -1038,14 +1049,63 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
   for (int i = 0; i < NS; i++) tot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
   const uint16_t* arow = act + (size_t)min(ml, Mt - 1) * astride + 8 * kq;
+#ifndef MI355Q_BURST_ANDOR
+#define MI355Q_BURST_ANDOR 1
+#endif
+#ifndef MI355Q_BURST_PF_BF
+#define MI355Q_BURST_PF_BF 1
+#endif
+#ifndef MI355Q_BURST_PF_SC
+#define MI355Q_BURST_PF_SC 1
+#endif
+  // (x & mask) | magic as ONE instruction (v_and_or_b32) per pair of weights: that form takes no literal
+  // operands, so both constants are put in registers behind the compiler's back; left to itself it emits
+  // v_and + v_or with literals, 11 instead of 7 instructions per packed dword
+  uint32_t magic_v = DT::int4_magic, nib_mask = 0x000F000Fu;
+#if MI355Q_BURST_ANDOR
+  asm volatile("" : "+v"(magic_v), "+s"(nib_mask));
+#endif
+  auto expand = [&](uint32_t wd) {
+    u32x4 r;
+    r[0] = (wd & nib_mask) | magic_v;
+    r[1] = ((wd >> 4) & nib_mask) | magic_v;
+    r[2] = ((wd >> 8) & nib_mask) | magic_v;
+    r[3] = ((wd >> 12) & nib_mask) | magic_v;
+    return r;
+  };
+  // What a chunk takes from LDS -- the activation fragments of its four k-steps, the scales of its group -- is
+  // requested before the first product: behind the scheduling fences below each read would otherwise be issued
+  // where its value is needed and the wave would stand through the LDS latency five times per chunk.  The
+  // widest variant with zero points has no registers left for that and keeps the reads in place.
+  constexpr bool ROOM = !(HAS_ZC && NS * CPW >= 14);
+  constexpr bool PF_BF = MI355Q_BURST_PF_BF && ROOM;
+  constexpr bool PF_SC = MI355Q_BURST_PF_SC && ROOM && !SMALLG;
 
   for (int burst = 0; burst < p.bursts; burst++) {
+    // lane offset of this burst's refills: past the strip once there is nothing left to ask for
+    const int refill_off = wlane + (burst + 1 < p.bursts ? 0 : 0x40000000);
 #pragma unroll
     for (int i = 0; i < CPW; i++) {
       const int c = cfirst + burst * CPW + i;
       f32x4 acc[NS], acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < NS; s++) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x4 bfr[4];
+      u32x2 svr[NS], zvr[NS];
+      if constexpr (PF_BF) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) bfr[ks] = *reinterpret_cast<const u32x4*>(arow + (c * 4 + ks) * 32);
+      }
+      if constexpr (PF_SC) {
+        const int g = (c * 4 + 3) / p.kpg;
+        const uint16_t* sg = sc_l + (size_t)g * SW + QW * kq;
+        const uint16_t* zg = zc_l + (size_t)g * SW + QW * kq;
+#pragma unroll
+        for (int sub = 0; sub < NS; sub++) {
+          svr[sub] = *reinterpret_cast<const u32x2*>(sg + 4 * sub);
+          if constexpr (HAS_ZC) zvr[sub] = *reinterpret_cast<const u32x2*>(zg + 4 * sub);
+        }
+      }
       // fold one scale group's sums into the totals: this lane's outputs are channels
       // QW kq + 4 sub + r of the strip
       auto flush = [&](int g) {
@@ -1053,9 +1113,14 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
         const uint16_t* zg = zc_l + (size_t)g * SW + QW * kq;
 #pragma unroll
         for (int sub = 0; sub < NS; sub++) {
-          const u32x2 sv = *reinterpret_cast<const u32x2*>(sg + 4 * sub);
-          u32x2 zv = u32x2{0u, 0u};
-          if constexpr (HAS_ZC) zv = *reinterpret_cast<const u32x2*>(zg + 4 * sub);
+          u32x2 sv, zv = u32x2{0u, 0u};
+          if constexpr (PF_SC) {
+            sv = svr[sub];
+            if constexpr (HAS_ZC) zv = zvr[sub];
+          } else {
+            sv = *reinterpret_cast<const u32x2*>(sg + 4 * sub);
+            if constexpr (HAS_ZC) zv = *reinterpret_cast<const u32x2*>(zg + 4 * sub);
+          }
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const uint32_t sw_ = sv[r >> 1];
@@ -1068,14 +1133,30 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
           }
         }
       };
+#ifdef MI355Q_BURST_NOCOMPUTE   // diagnostics: the weight stream alone (results are wrong)
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
-        const u32x4 bf = *reinterpret_cast<const u32x4*>(arow + (c * 4 + ks) * 32);
+      for (int pl = 0; pl < NS; pl++) acc1[0] += __uint_as_float((w[i][pl][0] ^ w[i][pl][1] ^ w[i][pl][2] ^ w[i][pl][3]) & 0x3fffffffu);
+      constexpr int KSTEPS = 0;
+#else
+      constexpr int KSTEPS = 4;
+#endif
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ks++) {
+        u32x4 bf;
+        if constexpr (PF_BF) bf = bfr[ks];
+        else bf = *reinterpret_cast<const u32x4*>(arow + (c * 4 + ks) * 32);
+#ifndef MI355Q_DIAG_NOONES
         acc1 = mfma16<DT>(ones, bf, acc1);
+#endif
 #pragma unroll
         for (int sub = 0; sub < NS; sub++) {
           const int e = ks * NS + sub;
-          acc[sub] = mfma16<DT>(dequant_frag<DT>(w[i][e >> 2][e & 3]), bf, acc[sub]);
+#ifdef MI355Q_DIAG_NODQ      // diagnostics: the products without the 4-bit expansion (results are wrong)
+          const uint32_t raw = w[i][e >> 2][e & 3];
+          acc[sub] = mfma16<DT>(u32x4{raw, raw, raw, raw}, bf, acc[sub]);
+#else
+          acc[sub] = mfma16<DT>(expand(w[i][e >> 2][e & 3]), bf, acc[sub]);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);  // dequantised fragments of one k-step live at a time
         if constexpr (SMALLG) {
@@ -1088,9 +1169,14 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
           }
         }
       }
+#ifdef MI355Q_DIAG_NOFLUSH   // diagnostics: no scale step (results are wrong)
+#pragma unroll
+      for (int sub = 0; sub < NS; sub++) tot[sub] += acc[sub];
+#else
       if constexpr (!SMALLG) flush((c * 4 + 3) / p.kpg);
+#endif
       // the slot just consumed is refilled at once: CPW chunks stay in flight per wave to the end
-      if (burst + 1 < p.bursts) issue_chunk(burst + 1, i);
+      issue_chunk(burst + 1, i, refill_off);
       // keep the chunks' MFMA chains apart: interleaving them would hold several accumulator sets live
       __builtin_amdgcn_sched_barrier(0);
     }
