@@ -726,10 +726,13 @@ static unsigned long long* g_burst_stamps = nullptr;
 
 constexpr int BURST_XV = 2;  // 16-byte activation vectors a thread may hold in the single-row prologue
 
+// threads a workgroup of the burst kernel may have: the deep rings need the registers of 512-thread workgroups
+constexpr int burst_threads(int ns, int cpw) { return (ns * cpw >= 7 && !(ns == 7 && cpw == 1)) ? 512 : 1024; }
+
 // SMALLG: scale groups of 32 or 64 input channels (one or two k-steps): the group sum is folded into
 // the total inside the k-step loop instead of once per 128-k chunk.
 template <typename DT, int NS, int CPW, bool HAS_ZC, int PRO, bool SMALLG = false>
-__global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel(const BurstParams p) {
+__global__ __launch_bounds__(burst_threads(NS, CPW)) void w4a16_burst_kernel(const BurstParams p) {
   constexpr int SW = 16 * NS, QW = 4 * NS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nw = p.nw, nthreads = nw * 64;
@@ -1224,9 +1227,9 @@ __global__ __launch_bounds__(NS * CPW >= 7 ? 512 : 1024) void w4a16_burst_kernel
 static bool burst_built(int ns, int cpw) {
   switch (ns) {
     case 1: return cpw == 2 || cpw == 4 || cpw == 7;
-    case 2: return cpw == 2 || cpw == 4;
+    case 2: return cpw == 1 || cpw == 2 || cpw == 4;
     case 4: return cpw == 2 || cpw == 4;
-    case 7: return cpw == 2;
+    case 7: return cpw == 1 || cpw == 2;
     default: return false;
   }
 }
@@ -1244,12 +1247,27 @@ static BurstPlan plan_burst(int M, int K, int G, int ns, bool has_zc) {
   BurstPlan bp{false, 0, 0, 0, 0, 0};
   if ((G % 128 && G != 64 && G != 32) || K % 128) return bp;
   const int chunks = K / 128, groups = K / G;
-  for (int nw = 16; nw >= 2 && !bp.ok; nw--) {
+  // experiments: MI355Q_BURST_NW / MI355Q_BURST_CPW force the waves per workgroup and the ring depth of
+  // strips of MI355Q_BURST_NS subtiles (0: every width) where the shape allows them
+  const int f_nw = env_int("MI355Q_BURST_NW", 0), f_cpw = env_int("MI355Q_BURST_CPW", 0), f_ns = env_int("MI355Q_BURST_NS", 0);
+  if (f_nw > 0 && f_cpw > 0 && (f_ns == 0 || f_ns == ns) && chunks % (f_nw * f_cpw) == 0 && burst_built(ns, f_cpw) &&
+      f_nw * 64 <= burst_threads(ns, f_cpw)) {
+    bp.ok = true; bp.nw = f_nw; bp.cpw = f_cpw; bp.bursts = chunks / (f_nw * f_cpw);
+  }
+  // 32-wide strips run fastest on 8 waves with two ring fills each (Llama-3-8B qkv_proj with the add + RMSNorm
+  // prologue, us: 16 waves x 2 chunks 6.6, 8 x 2 x 2 fills 6.1, 8 x 4 6.3, 4 x 4 x 2 6.5, 16 x 1 x 2 6.8); the other
+  // widths measured fastest with the most waves their ring depth allows
+  const int nw_max = (ns == 2 && chunks % 16 == 0 && !env_flag("MI355Q_BURST_WIDE_NS2")) ? 8 : 16;
+  for (int nw = nw_max; nw >= 2 && !bp.ok; nw--) {
     if (chunks % nw) continue;
     const int per = chunks / nw;
+    if (nw_max == 8 && nw == 8 && per % 2 == 0 && per >= 4) {   // two chunks in flight, refilled as they retire
+      bp.ok = true; bp.nw = 8; bp.cpw = 2; bp.bursts = per / 2;
+      break;
+    }
     for (int cpw = 8; cpw >= 2; cpw--) {
       if (per % cpw || !burst_built(ns, cpw)) continue;
-      if (cpw * ns >= 7 && nw > 8) continue;   // deep rings are built for 512-thread workgroups
+      if (nw * 64 > burst_threads(ns, cpw)) continue;   // deep rings run on 512-thread workgroups
       bp.ok = true; bp.nw = nw; bp.cpw = cpw; bp.bursts = per / cpw;
       break;
     }
@@ -1290,9 +1308,9 @@ template <typename DT, int PRO>
 static int launch_burst(const BurstParams& p, int ns, int cpw, size_t lds, hipStream_t stream) {
 #define MI355Q_B(n, c) if (ns == n && cpw == c) return launch_burst2<DT, n, c, PRO>(p, lds, stream)
   MI355Q_B(1, 2); MI355Q_B(1, 4); MI355Q_B(1, 7);
-  MI355Q_B(2, 2); MI355Q_B(2, 4);
+  MI355Q_B(2, 1); MI355Q_B(2, 2); MI355Q_B(2, 4);
   MI355Q_B(4, 2); MI355Q_B(4, 4);
-  MI355Q_B(7, 2);
+  MI355Q_B(7, 1); MI355Q_B(7, 2);
 #undef MI355Q_B
   return set_error(MI355Q_EINVAL, "w4a16_gemm: no burst kernel for strip %d, depth %d", 16 * ns, cpw);
 }
