@@ -124,6 +124,21 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// Wave sum without LDS permutes: four data-parallel moves inside each row of 16 lanes, then the two
+// row-swap instructions of gfx950 (each partner pair is added as own + partner, so every lane ends with the same
+// bits).  Deterministic, but associated differently from wave_sum: lanes pair 1, 2, 4, 8, 16, 32 apart in that order.
+__device__ inline float wave_sum_dpp(float v) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // lane ^ 1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // lane ^ 2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // the other quad of the half row
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // the other half row
+  u2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // Sum over a block of NW waves; every thread gets the total.  `scratch` holds NW floats.
 template <int NW>
 __device__ inline float block_sum(float v, float* scratch) {

@@ -855,7 +855,10 @@ __global__ __launch_bounds__(burst_threads(NS, CPW)) void w4a16_burst_kernel(con
 #define MI355Q_BURST_FP_SMALL -1
 #endif
   constexpr int FPB = MI355Q_BURST_FP == 0 ? RING : (MI355Q_BURST_FP == 1 ? FPW : (MI355Q_BURST_FP < 0 ? NS : MI355Q_BURST_FP));
-  constexpr int FPQ = (NS * CPW < 7 && MI355Q_BURST_FP_SMALL >= 0) ? (MI355Q_BURST_FP_SMALL == 0 ? RING : MI355Q_BURST_FP_SMALL) : FPB;
+  // 32-wide strips on 8 waves have 32 KiB per CU in their whole ring (4 KiB per wave): asked for at once, qkv_proj
+  // 5.9 -> 5.6 us; the 16-wide strips of o_proj, 16 waves, lose with the same change (4.35 -> 4.65)
+  constexpr int FPS = MI355Q_BURST_FP_SMALL >= 0 ? MI355Q_BURST_FP_SMALL : (NS == 2 ? 0 : -1);
+  constexpr int FPQ = (NS * CPW < 7 && FPS >= 0) ? (FPS == 0 ? RING : FPS) : FPB;
   constexpr int FP = FPQ < RING ? FPQ : RING;
   auto issue_plane = [&](int f) {   // plane f of the first ring fill
     const int i = f / NS, pl = f % NS;
@@ -913,7 +916,7 @@ __global__ __launch_bounds__(burst_threads(NS, CPW)) void w4a16_burst_kernel(con
           if (strip == 0 && p.res_out) *reinterpret_cast<u32x4*>(p.res_out + (size_t)row0 * p.K + 8 * v) = xa[i];
         }
       }
-      ss = wave_sum(ss);
+      ss = wave_sum_dpp(ss);
       if (lane == 0) red[wave] = ss;
       if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
       __syncthreads();
