@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--input-len", type=int, default=128)
-    ap.add_argument("--model", default=None, help="llama3-8b | llama3-70b | tiny (default: by --gpus)")
+    ap.add_argument("--model", default=None, help="llama3-8b | llama3-70b | mixtral-8x7b | tiny | small ... (default: by --gpus)")
+    ap.add_argument("--skip-configs", action="store_true", help="skip the other benchmark configurations (AWQ + fp8 KV, Mixtral)")
     ap.add_argument("--quant", default="gptq", choices=["gptq", "awq", "none"])
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"])
     ap.add_argument("--no-graph", action="store_true")
@@ -58,6 +59,8 @@ def time_dominant_kernel(runner, batch, reps=10):
     weights in the 256 MiB Infinity Cache."""
     from mi355q import ops
     from mi355q.model import linear_shapes, w4a16_bytes
+    if runner.cfg.num_experts:
+        return time_dominant_kernel_moe(runner, batch, reps)
     K, N = linear_shapes(runner.cfg, runner.tp_size)["gate_up"]
     x = (torch.randn((batch, K), device=runner.device) * 0.25).to(runner.dtype)
     layers = runner.layers
@@ -116,7 +119,58 @@ def time_dominant_kernel(runner, batch, reps=10):
             "launches": len(times) * passes * len(layers)}
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r2", "decode_8b_gptq_pmc_fetch_write.json")
+def time_dominant_kernel_moe(runner, batch, reps=10):
+    """The same measurement for a routed-experts model: the merged gate / up projection of the selected
+    experts (one launch over the batch x top_k slots, SiluAndMul in its epilogue), every layer's experts in
+    turn so that no launch finds its weights cached."""
+    from mi355q import ops
+    cfg = runner.cfg
+    blk0 = runner.layers[0]["moe"]
+    w13 = blk0.w13
+    x = (torch.randn((batch, w13.K), device=runner.device) * 0.25).to(runner.dtype)
+    slots = batch * cfg.top_k
+    ids = (torch.arange(slots, device=runner.device, dtype=torch.int32) * 3) % w13.E   # distinct experts while slots <= E
+
+    def launch(L):
+        return ops.moe_w4a16_gemm(x, L["moe"].w13, ids, cfg.top_k, silu_pairs=L["moe"].w13.pair_halves)
+
+    for L in runner.layers[:2]:
+        launch(L)
+    torch.cuda.synchronize()
+    passes = 4
+    stream = torch.cuda.Stream(device=runner.device)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        launch(runner.layers[0])
+        stream.synchronize()
+        with torch.cuda.graph(graph, stream=stream):
+            for _ in range(passes):
+                for L in runner.layers:
+                    launch(L)
+        graph.replay()
+        stream.synchronize()
+        times = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            graph.replay()
+            b.record(stream)
+            stream.synchronize()
+            times.append(a.elapsed_time(b) * 1e-3 / (passes * len(runner.layers)))
+    avg = sum(times) / len(times)
+    G = w13.G
+    per_expert = w13.K * w13.N // 2 + (w13.K // G) * w13.N * 2 + ((w13.K // G) * w13.N // 2 if w13.zc is not None else 0)
+    nbytes = min(slots, w13.E) * per_expert + batch * w13.K * 2 + slots * (w13.N // 2 if w13.pair_halves else w13.N) * 2
+    return {"bound": "hbm", "achieved": nbytes / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": nbytes / avg / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": "no counter passes for this workload",
+            "frac_of_measured_stream_peak": nbytes / avg / 1e9 / STREAM_PEAK_GBS,
+            "kernel": "w4a16_burst_kernel with the expert indirection (experts' gate_up %dx%d + SiLU epilogue, %d slots)"
+                      % (w13.K, w13.N, slots),
+            "bytes_per_launch": nbytes, "avg_launch_us": avg * 1e6, "min_launch_us": min(times) * 1e6,
+            "launches": len(times) * passes * len(runner.layers)}
+
+
+PMC_FILE = os.path.join(ROOT, "profiles", "r3", "decode_8b_gptq_pmc_fetch_write.json")
 KERNEL_SOURCES = ("vllm-fork_amd/csrc/w4a16.hip", "vllm-fork_amd/csrc/common.h")
 
 
@@ -403,7 +457,7 @@ def main():
     if rank == 0 and n_gpus == 1 and not args.skip_cpu:
         out["cpu_baseline"] = cpu_baseline(cfg, G, B)
         out["cpu_baseline_opt125m"] = cpu_baseline_opt125m()
-    if rank == 0 and n_gpus == 1 and args.quant != "none" and not args.skip_bf16:
+    if rank == 0 and n_gpus == 1 and args.quant != "none" and not args.skip_bf16 and not cfg.num_experts:
         # the same harness on the unquantized model: the "x its own bf16 decode" comparator
         runner = None
         torch.cuda.empty_cache()
@@ -455,6 +509,51 @@ def main():
                                         "ttft_ms_p50": statistics.median(ts) * 1e3,
                                         "step_hbm_frac": bytes2 / s2 / 1e9 / HBM_PEAK_GBS})
             del r2
+    if rank == 0 and n_gpus == 1 and not dist_on and not args.skip_configs and model == "llama3-8b" and args.quant == "gptq" \
+            and (B, in_len) == (1, 128):
+        # the benchmark's other single-GPU configurations, same harness, short runs: Llama-3-8B AWQ int4 with an
+        # fp8 KV cache (hipGraph decode) and Mixtral 8x7B AWQ int4 (routed experts), batch 1
+        runner = r16 = r2 = None
+        out["other_configs"] = []
+        for m2, q2, kv2, in2 in (("llama3-8b", "awq", "fp8", 128), ("llama3-8b", "awq", "fp8", 2048),
+                                 ("mixtral-8x7b", "awq", "auto", 128)):
+            torch.cuda.empty_cache()
+            cfg2 = CONFIGS[m2]
+            ml2 = (in2 + 4 + 32 + 8 + 255) // 256 * 256
+            r2 = LlamaRunner(cfg2, quant=q2, kv_cache_dtype=kv2, group_size=G, device=dev, max_batch=1, max_seq_len=ml2)
+            p2 = torch.randint(0, min(10000, cfg2.vocab), (1, in2), generator=torch.Generator().manual_seed(0))
+            ts = []
+            for i in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r2.prefill(p2)
+                torch.cuda.synchronize()
+                if i >= 2:
+                    ts.append(time.perf_counter() - t0)
+            g2 = graph
+            if g2:
+                try:
+                    r2.capture()
+                except Exception as e:  # noqa: BLE001
+                    g2 = False
+                    r2.graph = None
+                    print(f"[bench] {m2}: graph capture failed ({type(e).__name__}: {e}); eager", file=sys.stderr)
+            for _ in range(4):
+                r2.decode_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(32):
+                r2.decode_step()
+            torch.cuda.synchronize()
+            s2 = (time.perf_counter() - t0) / 32
+            bytes2 = decode_bytes_per_step(cfg2, 1, in2 + 4 + 16, G, q2 == "awq", 1 if kv2 == "fp8" else 2, 1)
+            out["other_configs"].append({
+                "workload": "%s %s-int4 g128 decode, TP=1, batch 1, prompt %d, %s KV, %s" % (
+                    m2, q2, in2, "fp8-e4m3" if kv2 == "fp8" else "bf16", "hipGraph" if g2 else "eager"),
+                "tok_s": 1 / s2, "ms_per_step": s2 * 1e3, "ttft_ms_p50": statistics.median(ts) * 1e3,
+                "step_bytes": bytes2, "step_hbm_frac": bytes2 / s2 / 1e9 / HBM_PEAK_GBS})
+            del r2
+            r2 = None
     if rank == 0:
         print(json.dumps(out))
     if dist_on:

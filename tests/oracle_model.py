@@ -21,6 +21,17 @@ def _gemm(lin, x):
                           zp_mode=orc.ZP_AWQ)
 
 
+def _moe(blk, x):
+    """The sparse block of mixtral.py:126-130 with the oracle's pieces: 16-bit router, fp32 softmax top-k with
+    renormalisation, experts and weighted sum as tests/kernels/utils.py:912-1078 states them."""
+    import moe_ref
+    (q13, s13, z13), (q2, s2, z2) = blk.checkpoint
+    logits = orc.linear_h16(x, _bits(blk.router))
+    w, ids = moe_ref.route(logits, blk.top_k, renormalize=True)
+    np_ = lambda t: None if t is None else t.numpy()
+    return moe_ref.moe(x, (q13.numpy(), _bits(s13), np_(z13)), (q2.numpy(), _bits(s2), np_(z2)), w, ids, blk.G)
+
+
 def assert_tokens_match(got, want, logits):
     """got/want: [step][sequence] token ids; logits: [step][sequence] fp32 oracle logits.  Tokens must
     agree, except that a sequence may leave the oracle's path at a near-tie: fp32 sums are not
@@ -77,6 +88,9 @@ def oracle_generate(runner, prompt, n_new, with_logits=False):
                                        runner.scale, fp8=fp8, k_scale=ks, v_scale=vs)
             o = _gemm(L["o"], attn.reshape(1, H * D))
             o, residual = orc.fused_add_rms_norm(o, residual, _bits(L["ln2"]), eps)
+            if "moe" in L:
+                h = _moe(L["moe"], o)
+                continue
             gu = _gemm(L["gate_up"], o)
             h = _gemm(L["down"], orc.silu_and_mul(gu))
         hn, _ = orc.fused_add_rms_norm(h, residual, _bits(runner.norm), eps)

@@ -6,7 +6,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("quant,kv,model", [("gptq", "auto", "tiny"), ("awq", "fp8", "tiny"), ("gptq", "fp8", "tiny"),
-                                            ("gptq", "auto", "small"), ("awq", "fp8", "small")])
+                                            ("gptq", "auto", "small"), ("awq", "fp8", "small"),
+                                            ("awq", "auto", "tiny-moe"), ("gptq", "fp8", "small-moe"), ("awq", "fp8", "small-moe")])
 def test_greedy_tokens_match_oracle(quant, kv, model, monkeypatch):
     from mi355q import ops
     from mi355q.model import CONFIGS, LlamaRunner
@@ -16,7 +17,8 @@ def test_greedy_tokens_match_oracle(quant, kv, model, monkeypatch):
     cfg = CONFIGS[model]   # "small" is wide enough for the burst kernels and the fused gate_up + SiLU
     runner = LlamaRunner(cfg, quant=quant, kv_cache_dtype=kv, device="cuda:0", max_batch=2, max_seq_len=64,
                          keep_checkpoint=True, seed=3)
-    assert runner.layers[0]["gate_up"].w.pair_halves == (model == "small")
+    if not cfg.num_experts:
+        assert runner.layers[0]["gate_up"].w.pair_halves == (model == "small")
     prompt = torch.randint(0, cfg.vocab, (2, 21), generator=torch.Generator().manual_seed(1))
     got = [runner.prefill(prompt).cpu().tolist()]
     runner.capture()
@@ -51,6 +53,29 @@ def test_batch_decode_tokens_match_oracle(batch, quant, kv, monkeypatch):
     # a sequence that left the oracle's path at a near-tie (allowed above) counts as different from there on
     same = sum(g == w for step_g, step_w in zip(got, want) for g, w in zip(step_g, step_w))
     assert same >= 0.8 * 4 * batch and got[0] == want[0] or same >= 0.85 * 4 * batch
+
+
+def test_mixtral_width_decode_matches_oracle(monkeypatch):
+    """Routed experts end to end at Mixtral 8x7B's widths (E = 8, top-2, H = 4096, I = 14336, vocabulary 32000, two
+    layers, AWQ experts with zero points): router GEMV, softmax top-k with renormalisation, the selected experts'
+    4-bit GEMVs and the weighted sum inside the captured decode step, greedy tokens against the oracle model
+    (mixtral.py:126-130, moe_wna16.py:516-638, fused_moe.py:1650-1850)."""
+    from mi355q import ops
+    from mi355q.model import CONFIGS, LlamaRunner
+    from oracle_model import assert_tokens_match, oracle_generate
+    monkeypatch.setattr(ops, "DEQUANT_MATMUL_MIN_TOKENS", 1 << 30)
+    cfg = CONFIGS["mixtral-2l"]
+    runner = LlamaRunner(cfg, quant="awq", kv_cache_dtype="fp8", device="cuda:0", max_batch=1, max_seq_len=32,
+                         keep_checkpoint=True, seed=11)
+    prompt = torch.randint(0, cfg.vocab, (1, 3), generator=torch.Generator().manual_seed(6))
+    got = [runner.prefill(prompt).cpu().tolist()]
+    runner.capture()
+    for _ in range(3):
+        runner.decode_step()
+        got.append(runner.tokens.cpu().tolist())
+    want, logits = oracle_generate(runner, prompt, 4, with_logits=True)
+    assert_tokens_match(got, want, logits)
+    assert got[0] == want[0]
 
 
 def test_graph_and_eager_decode_agree():

@@ -1,11 +1,14 @@
-"""Llama-architecture decode/prefill runner built only from mi355q ops.
+"""Llama / Mixtral-architecture decode/prefill runner built only from mi355q ops.
 
 This is the harness the benchmark and the end-to-end tests drive: the layer order of
 vllm/model_executor/models/llama.py:311-328 (RMSNorm -> qkv_proj -> RoPE -> KV-cache
 write -> attention -> o_proj -> fused add+RMSNorm -> gate_up_proj -> SiluAndMul ->
 down_proj), GPTQ/AWQ 4-bit linears, a 16-bit lm_head and greedy sampling, with the
 column/row tensor-parallel split of vllm/model_executor/layers/linear.py (all-reduce
-after o_proj and down_proj, linear.py:1763-1767).  Weights are synthetic.
+after o_proj and down_proj, linear.py:1763-1767).  Configurations with experts replace the MLP by the
+sparse block of vllm/model_executor/models/mixtral.py:126-130 (16-bit router, softmax top-k with
+renormalisation, 4-bit experts in the MoE WNA16 layout of
+vllm/model_executor/layers/quantization/moe_wna16.py:204-360, weighted sum).  Weights are synthetic.
 """
 import os
 from dataclasses import dataclass
@@ -28,6 +31,8 @@ class LlamaConfig:
     rope_theta: float = 500000.0
     rms_eps: float = 1e-5
     max_pos: int = 8192
+    num_experts: int = 0       # > 0: the MLP is a routed-experts block (Mixtral)
+    top_k: int = 0
 
 
 # token counts up to which add+RMSNorm runs in the prologue of the GEMM that consumes it: every
@@ -40,6 +45,13 @@ CONFIGS = {
     "llama3-70b": LlamaConfig("llama3-70b", 8192, 28672, 80, 64, 8, 128, 128256),
     "tiny": LlamaConfig("tiny", 256, 512, 2, 4, 2, 64, 1024, max_pos=512),
     "small": LlamaConfig("small", 1024, 2048, 2, 8, 2, 128, 2048, max_pos=512),
+    "mixtral-8x7b": LlamaConfig("mixtral-8x7b", 4096, 14336, 32, 32, 8, 128, 32000, rope_theta=1e6, max_pos=8192,
+                                num_experts=8, top_k=2),
+    "tiny-moe": LlamaConfig("tiny-moe", 256, 512, 2, 4, 2, 64, 1024, max_pos=512, num_experts=4, top_k=2),
+    "small-moe": LlamaConfig("small-moe", 1024, 2048, 2, 8, 2, 128, 2048, max_pos=512, num_experts=8, top_k=2),
+    # Mixtral's widths on two layers: the expert kernels at full size in an end-to-end test
+    "mixtral-2l": LlamaConfig("mixtral-2l", 4096, 14336, 2, 32, 8, 128, 32000, rope_theta=1e6, max_pos=2048,
+                              num_experts=8, top_k=2),
 }
 
 
@@ -63,8 +75,14 @@ def decode_bytes_per_step(cfg: LlamaConfig, batch: int, ctx: int, G: int, zeros:
     """Algorithmic HBM bytes of one decode step on one rank: quantized linears, 16-bit lm_head,
     and the KV cache read at context `ctx` (norm/activation traffic is < 1 MB and left out)."""
     total = 0
-    for K, N in linear_shapes(cfg, tp).values():
-        total += K * N // 2 + (K // G) * N * 2 + ((K // G) * N // 2 if zeros else 0)
+    for name, (K, N) in linear_shapes(cfg, tp).items():
+        one = K * N // 2 + (K // G) * N * 2 + ((K // G) * N // 2 if zeros else 0)
+        if cfg.num_experts and name in ("gate_up", "down"):
+            # experts a step touches: every (token, selected expert) slot reads its expert, at most all of them
+            one *= min(cfg.num_experts, max(batch, 1) * cfg.top_k)
+        total += one
+    if cfg.num_experts:
+        total += cfg.num_experts * cfg.hidden * 2          # 16-bit router
     total *= cfg.layers
     total += cfg.vocab // tp * cfg.hidden * 2
     kvh = max(cfg.kv_heads // tp, 1)
@@ -174,6 +192,50 @@ class Linear16:
         return torch.nn.functional.linear(x, self.weight)
 
 
+class MoeBlock:
+    """Routed experts of one decoder layer: a 16-bit router [E, H] and 4-bit experts generated directly in
+    the layout the MoE WNA16 loader leaves them in (moe_wna16.py:516-638): w13 uint8 [E, 2I, H/2] (gate rows,
+    then up rows; two values per byte along the input dimension, even index low), scales [E, 2I, H/G], zero
+    points uint8 [E, I, H/G] for AWQ; w2 likewise [E, H, I/2].  Under tensor parallelism the intermediate
+    dimension is cut as the loader cuts it (w1 / w3 rows, w2 input columns) and the block's output is
+    all-reduced by the caller."""
+
+    def __init__(self, cfg: LlamaConfig, G: int, dtype, device, gen, asym: bool, tp_rank: int = 0, tp_size: int = 1,
+                 keep_checkpoint: bool = False):
+        E, H, I = cfg.num_experts, cfg.hidden, cfg.inter
+        assert I % tp_size == 0 and (I // tp_size) % G == 0 and H % G == 0, "expert shards must hold whole scale groups"
+        self.top_k, self.G = cfg.top_k, G
+        self.router = (torch.randn((E, H), device=device, generator=gen) * (1.0 / H ** 0.5)).to(dtype)
+        Il = I // tp_size
+
+        def tensors(n, k, gain):
+            qw = torch.randint(0, 256, (E, n, k // 2), dtype=torch.uint8, device=device, generator=gen)
+            sc = ((gain / (21.25 * k) ** 0.5) * (0.5 + torch.rand((E, n, k // G), device=device, generator=gen))).to(dtype)
+            qz = torch.randint(0, 256, (E, n // 2, k // G), dtype=torch.uint8, device=device, generator=gen) if asym else None
+            return qw, sc, qz
+
+        w13, w2 = tensors(2 * I, H, 1.0), tensors(H, I, 0.5)
+        if tp_size > 1:
+            rows = lambda t, per: torch.cat((t[:, tp_rank * per:(tp_rank + 1) * per],
+                                             t[:, t.shape[1] // 2 + tp_rank * per:t.shape[1] // 2 + (tp_rank + 1) * per]), 1)
+            w13 = (rows(w13[0], Il), rows(w13[1], Il), None if w13[2] is None else rows(w13[2], Il // 2))
+            cols = lambda t, per: t[:, :, tp_rank * per:(tp_rank + 1) * per].contiguous()
+            w2 = (cols(w2[0], Il // 2), cols(w2[1], Il // G), None if w2[2] is None else cols(w2[2], Il // G))
+        self.w13 = ops.moe_w4a16_repack(w13[0], w13[1], w13[2], G, pair_halves=True)
+        self.w2 = ops.moe_w4a16_repack(w2[0], w2[1], w2[2], G)
+        self.checkpoint = None
+        if keep_checkpoint:
+            cpu = lambda w: tuple(None if t is None else t.cpu() for t in w)
+            self.checkpoint = (cpu(w13), cpu(w2))
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        from .plugin.moe import fused_experts, fused_topk
+        T = x.shape[0]
+        logits = ops.linear_skinny(x, self.router) if T <= 16 else torch.nn.functional.linear(x, self.router)
+        w, ids = fused_topk(logits, self.top_k, True)      # Mixtral renormalises the selected weights
+        return fused_experts(x, self.w13, self.w2, w, ids)
+
+
 class LlamaRunner:
     def __init__(self, cfg: LlamaConfig, quant: str = "gptq", kv_cache_dtype: str = "auto", group_size: int = 128,
                  dtype=torch.bfloat16, device="cuda:0", tp_rank: int = 0, tp_size: int = 1, tp_group=None,
@@ -222,14 +284,19 @@ class LlamaRunner:
 
         self.layers = []
         for _ in range(cfg.layers):
-            self.layers.append({
+            L = {
                 "ln1": torch.ones(cfg.hidden, dtype=dtype, device=self.device),
                 "ln2": torch.ones(cfg.hidden, dtype=dtype, device=self.device),
                 "qkv": make("qkv"),
                 "o": make("o", gain=0.5),
-                "gate_up": make("gate_up", pair_halves=pair),
-                "down": make("down", gain=0.5),
-            })
+            }
+            if cfg.num_experts:
+                assert quant != "none", "the routed-experts block is built for 4-bit experts"
+                L["moe"] = MoeBlock(cfg, self.G, dtype, self.device, gen, quant == "awq", tp_rank, tp_size, keep_checkpoint)
+            else:
+                L["gate_up"] = make("gate_up", pair_halves=pair)
+                L["down"] = make("down", gain=0.5)
+            self.layers.append(L)
         self.norm = torch.ones(cfg.hidden, dtype=dtype, device=self.device)
         vshard = cfg.vocab // tp_size
         # embedding replicated, lm_head vocab-parallel (rows of one full matrix)
@@ -350,6 +417,10 @@ class LlamaRunner:
             o = ops.w4a16_mm_add_rms_norm(attn.view(T, qs), L["o"].w, residual, L["ln2"], cfg.rms_eps)
         else:
             o = self._all_reduce(L["o"](attn.view(T, qs)))
+        if "moe" in L:   # router, top-k, experts, weighted sum (mixtral.py:126-130); all-reduce of the partial sums
+            if not o_normed:
+                ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
+            return self._all_reduce(L["moe"](o)), residual, False
         tail = next_norm is not None and self._tail_norm_ok(T, L["down"]) if self.quant != "none" else False
 
         def down(act, **kw):
