@@ -511,6 +511,20 @@ int mi355q_reshape_and_cache(const void* key, const void* value, int64_t key_str
                              int head_size, int block_size, int64_t block_stride, int dtype,
                              int kv_fp8, const float* k_scale, const float* v_scale,
                              mi355q_stream_t stream);
+/* The same write for the flash cache layouts: key_cache and value_cache both
+ * [blocks, block_size, heads, head] (NHD) or [blocks, heads, block_size, head] (HND), described by the
+ * element strides of the block, token-row (page) and head dimensions; k_scale / v_scale DEVICE fp32, one
+ * value (scales_per_head = 0) or one per head (1).  slot_mapping int64 [T], negative = skip; T may be
+ * smaller than the key tensor's first dimension (graph padding), as in the reference.
+ * Replaces ops.reshape_and_cache_flash (vllm/_custom_ops.py:2614-2637;
+ * cache_kernels.cu:314-400,795-867). */
+int mi355q_reshape_and_cache_flash(const void* key, const void* value, int64_t key_stride,
+                                   int64_t value_stride, void* key_cache, void* value_cache,
+                                   const int64_t* slot_mapping, int num_tokens, int num_heads,
+                                   int head_size, int block_size, int64_t block_stride,
+                                   int64_t page_stride, int64_t head_stride, int dtype, int kv_fp8,
+                                   const float* k_scale, const float* v_scale, int scales_per_head,
+                                   mi355q_stream_t stream);
 /* mi355q_rotary_embedding followed by mi355q_reshape_and_cache in one launch: q and k are rotated in
  * place, the rotated k and v are written to the paged cache (same layouts, same fp8 conversion; a
  * negative slot rotates the token without caching it).  Replaces the backend hook

@@ -283,6 +283,25 @@ def reshape_and_cache(key, value, kc, vc, slot_mapping, fp8=False, k_scale=1.0, 
                                 _i(dt))
 
 
+def reshape_and_cache_flash(key, value, kc, vc, slot_mapping, hnd=False, fp8=False, k_scale=(1.0,), v_scale=(1.0,),
+                            dt=BF16):
+    """kc / vc: [blocks, bs, heads, head] (hnd=False) or [blocks, heads, bs, head] (hnd=True) arrays, written in
+    place; k_scale / v_scale: one value or one per head."""
+    key = np.ascontiguousarray(key, dtype=np.uint16)
+    value = np.ascontiguousarray(value, dtype=np.uint16)
+    T, heads, head = key.shape
+    bs = kc.shape[2] if hnd else kc.shape[1]
+    block_stride = bs * heads * head
+    page_stride, head_stride = (head, bs * head) if hnd else (heads * head, head)
+    sm = np.ascontiguousarray(slot_mapping, dtype=np.int64)
+    ks = np.ascontiguousarray(k_scale, dtype=np.float32).reshape(-1)
+    vs = np.ascontiguousarray(v_scale, dtype=np.float32).reshape(-1)
+    assert ks.size == vs.size and ks.size in (1, heads)
+    lib().orc_reshape_and_cache_flash(_p(key), _p(value), _p(kc), _p(vc), _p(sm), _i(len(sm)), _i(heads), _i(head), _i(bs),
+                                      ctypes.c_int64(block_stride), ctypes.c_int64(page_stride), ctypes.c_int64(head_stride),
+                                      _i(int(fp8)), _p(ks), _p(vs), _i(int(ks.size > 1)), _i(dt))
+
+
 def paged_attention(q, kc, vc, block_tables, seq_lens, scale, alibi=None, fp8=False, k_scale=1.0,
                     v_scale=1.0, dt=BF16):
     q = np.ascontiguousarray(q, dtype=np.uint16)

@@ -530,6 +530,38 @@ def test_silu_and_mul():
 # ---------------------------------------------------------------------------
 # KV cache + paged attention
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("fp8,per_head", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("hnd", [False, True])
+@pytest.mark.parametrize("bs,head", [(16, 128), (32, 64), (16, 120)])
+def test_reshape_and_cache_flash(fp8, per_head, hnd, bs, head):
+    """ops.reshape_and_cache_flash (tests/kernels/attention/test_cache.py:184-330 of the reference: NHD and HND
+    storage, fp8 with one scale or one per head, padded slots) bit for bit against the oracle's scatter; the key
+    tensor carries more rows than slot_mapping, as under graph padding."""
+    rng = np.random.default_rng(7 + bs + head)
+    T, heads, nblk = 11, 3, 5
+    key = orc.f32_to_h16(rng.standard_normal((T + 2, heads, head)).astype(np.float32))
+    val = orc.f32_to_h16(rng.standard_normal((T + 2, heads, head)).astype(np.float32))
+    slots = rng.permutation(nblk * bs)[:T].astype(np.int64)
+    slots[4] = -1
+    cdt, tdt = (np.uint8, torch.uint8) if fp8 else (np.uint16, torch.bfloat16)
+    shape = (nblk, heads, bs, head) if hnd else (nblk, bs, heads, head)
+    kc_ref, vc_ref = np.zeros(shape, dtype=cdt), np.zeros(shape, dtype=cdt)
+    ks = rng.uniform(0.02, 0.08, heads if per_head else 1).astype(np.float32) if fp8 else np.ones(1, np.float32)
+    vs = rng.uniform(0.02, 0.08, heads if per_head else 1).astype(np.float32) if fp8 else np.ones(1, np.float32)
+    orc.reshape_and_cache_flash(key[:T], val[:T], kc_ref, vc_ref, slots, hnd=hnd, fp8=fp8, k_scale=ks, v_scale=vs)
+    kc, vc = torch.zeros(shape, dtype=tdt, device=DEV), torch.zeros(shape, dtype=tdt, device=DEV)
+    kview, vview = (kc.permute(0, 2, 1, 3), vc.permute(0, 2, 1, 3)) if hnd else (kc, vc)   # [blocks, bs, heads, head]
+    ops.reshape_and_cache_flash(to_dev(key), to_dev(val), kview, vview, torch.from_numpy(slots).to(DEV),
+                                "fp8" if fp8 else "auto", torch.from_numpy(ks).to(DEV), torch.from_numpy(vs).to(DEV))
+    got_k = kc.cpu().numpy() if fp8 else to_bits(kc)
+    got_v = vc.cpu().numpy() if fp8 else to_bits(vc)
+    assert np.array_equal(got_k, kc_ref) and np.array_equal(got_v, vc_ref)
+    assert kc_ref.any() and not np.array_equal(kc_ref, vc_ref)
+    with pytest.raises(RuntimeError, match="shape \\[1\\] or \\[num_heads\\]"):
+        ops.reshape_and_cache_flash(to_dev(key), to_dev(val), kview, vview, torch.from_numpy(slots).to(DEV), "fp8",
+                                    torch.ones(2, device=DEV), torch.ones(2, device=DEV))
+
+
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("bs,head", [(16, 128), (32, 64)])
 def test_reshape_and_cache(fp8, bs, head):

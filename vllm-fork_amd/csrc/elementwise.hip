@@ -341,6 +341,48 @@ __global__ void reshape_and_cache_kernel(const uint16_t* __restrict__ key,
   }
 }
 
+// The same write for the flash layouts: both caches [blocks, block_size, heads, head] (NHD) or
+// [blocks, heads, block_size, head] (HND), told apart by the strides; one scale per tensor or one per head.
+// A head's elements are contiguous in source and cache, so a work item moves 8 of them (16 bytes in, 16 or 8 out).
+template <typename DT, bool FP8>
+__global__ void reshape_and_cache_flash_kernel(const uint16_t* __restrict__ key, const uint16_t* __restrict__ value,
+                                               int64_t key_stride, int64_t value_stride, void* __restrict__ kc,
+                                               void* __restrict__ vc, const int64_t* __restrict__ slot_mapping,
+                                               int heads, int head, int bs, int64_t block_stride, int64_t page_stride,
+                                               int64_t head_stride, const float* __restrict__ k_scale,
+                                               const float* __restrict__ v_scale, int scale_stride) {
+  const int64_t slot = slot_mapping[blockIdx.x];
+  if (slot < 0) return;
+  const int64_t b = slot / bs, o = slot % bs;
+  const int vph = head >> 3;   // 8-element vectors per head
+  for (int idx = threadIdx.x; idx < heads * vph; idx += blockDim.x) {
+    const int h = idx / vph, d = (idx - h * vph) * 8;
+    const u32x4 kv = *reinterpret_cast<const u32x4*>(key + (size_t)blockIdx.x * key_stride + (size_t)h * head + d);
+    const u32x4 vv = *reinterpret_cast<const u32x4*>(value + (size_t)blockIdx.x * value_stride + (size_t)h * head + d);
+    const size_t dst = (size_t)b * block_stride + (size_t)o * page_stride + (size_t)h * head_stride + d;
+    if constexpr (FP8) {
+      const float ks = k_scale[h * scale_stride], vs = v_scale[h * scale_stride];
+      auto enc8 = [&](const u32x4 x, float sc) {
+        u32x2 r;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const uint32_t a = x[2 * e], c = x[2 * e + 1];
+          r[e] = (uint32_t)f32_to_fp8(DT::to_f32((uint16_t)(a & 0xffff)) / sc) |
+                 ((uint32_t)f32_to_fp8(DT::to_f32((uint16_t)(a >> 16)) / sc) << 8) |
+                 ((uint32_t)f32_to_fp8(DT::to_f32((uint16_t)(c & 0xffff)) / sc) << 16) |
+                 ((uint32_t)f32_to_fp8(DT::to_f32((uint16_t)(c >> 16)) / sc) << 24);
+        }
+        return r;
+      };
+      *reinterpret_cast<u32x2*>(reinterpret_cast<uint8_t*>(kc) + dst) = enc8(kv, ks);
+      *reinterpret_cast<u32x2*>(reinterpret_cast<uint8_t*>(vc) + dst) = enc8(vv, vs);
+    } else {
+      *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(kc) + dst) = kv;
+      *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(vc) + dst) = vv;
+    }
+  }
+}
+
 // RoPE on q and k (in place) and the KV-cache write of the rotated k and of v in one pass over the
 // token: what rotary_kernel followed by reshape_and_cache_kernel leave behind, bit for bit (the cache
 // receives k as rounded to the activation dtype by the rotation).  Tokens whose slot is negative are
@@ -917,6 +959,43 @@ extern "C" int mi355q_reshape_and_cache(const void* key, const void* value, int6
                                            block_size, block_stride, k_scale, v_scale));
   }
   return check_launch("reshape_and_cache_kernel");
+}
+
+extern "C" int mi355q_reshape_and_cache_flash(const void* key, const void* value, int64_t key_stride,
+                                              int64_t value_stride, void* key_cache, void* value_cache,
+                                              const int64_t* slot_mapping, int num_tokens, int num_heads,
+                                              int head_size, int block_size, int64_t block_stride,
+                                              int64_t page_stride, int64_t head_stride, int dtype, int kv_fp8,
+                                              const float* k_scale, const float* v_scale, int scales_per_head,
+                                              mi355q_stream_t stream) {
+  if (int e = check_h16(dtype, "reshape_and_cache_flash")) return e;
+  if (num_tokens == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(key && value && key_cache && value_cache && slot_mapping, "reshape_and_cache_flash: null pointer");
+  MI355Q_REQUIRE(head_size > 0 && head_size % 8 == 0, "reshape_and_cache_flash: head_size %d must be a multiple of 8", head_size);
+  MI355Q_REQUIRE(num_heads > 0 && block_size > 0, "reshape_and_cache_flash: heads %d, block size %d", num_heads, block_size);
+  MI355Q_REQUIRE(key_stride % 8 == 0 && value_stride % 8 == 0 && ((((uintptr_t)key | (uintptr_t)value)) & 15) == 0,
+                 "reshape_and_cache_flash: key / value rows must be 16-byte aligned");
+  const int eb = kv_fp8 ? 1 : 2, al = kv_fp8 ? 7 : 15;
+  MI355Q_REQUIRE((((uintptr_t)key_cache | (uintptr_t)value_cache) & al) == 0 && (block_stride * eb) % (al + 1) == 0 &&
+                     (page_stride * eb) % (al + 1) == 0 && (head_stride * eb) % (al + 1) == 0,
+                 "reshape_and_cache_flash: cache strides must keep heads %d-byte aligned", al + 1);
+  if (kv_fp8) MI355Q_REQUIRE(k_scale && v_scale, "reshape_and_cache_flash: fp8 cache needs k_scale/v_scale");
+  int threads = num_heads * (head_size / 8);
+  threads = threads > 512 ? 512 : (threads + 63) / 64 * 64;
+  hipStream_t s = (hipStream_t)stream;
+  const int ss = scales_per_head ? 1 : 0;
+  if (kv_fp8) {
+    DISPATCH_H16(dtype, hipLaunchKernelGGL((reshape_and_cache_flash_kernel<DT, true>), dim3(num_tokens), dim3(threads), 0, s,
+                                           (const uint16_t*)key, (const uint16_t*)value, key_stride, value_stride, key_cache,
+                                           value_cache, slot_mapping, num_heads, head_size, block_size, block_stride,
+                                           page_stride, head_stride, k_scale, v_scale, ss));
+  } else {
+    DISPATCH_H16(dtype, hipLaunchKernelGGL((reshape_and_cache_flash_kernel<DT, false>), dim3(num_tokens), dim3(threads), 0, s,
+                                           (const uint16_t*)key, (const uint16_t*)value, key_stride, value_stride, key_cache,
+                                           value_cache, slot_mapping, num_heads, head_size, block_size, block_stride,
+                                           page_stride, head_stride, k_scale, v_scale, ss));
+  }
+  return check_launch("reshape_and_cache_flash_kernel");
 }
 
 extern "C" int mi355q_rope_and_cache(const int64_t* positions, void* query, int64_t query_stride, void* key,

@@ -91,6 +91,8 @@ _SIGS = {
     "mi355q_silu_and_mul_pairs": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "mi355q_reshape_and_cache": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int,
                                          c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    "mi355q_reshape_and_cache_flash": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                               c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "mi355q_rope_and_cache": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_int,
                                       c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_int, c_int, c_vp, c_vp,
                                       c_vp]),

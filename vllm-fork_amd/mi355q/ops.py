@@ -967,6 +967,30 @@ def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, kv_cache
         _dt(key), int(_is_fp8(kv_cache_dtype)), _ptr(k_scale), _ptr(v_scale), _stream()))
 
 
+def reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype: str, k_scale, v_scale) -> None:
+    """ops.reshape_and_cache_flash (vllm/_custom_ops.py:2614-2637).  key/value [T, heads, head]; both caches
+    [blocks, block_size, heads, head], or the [blocks, heads, block_size, head] storage viewed that way (the
+    strides tell); k_scale / v_scale hold one value or one per head."""
+    _need_cuda(key, value, key_cache, value_cache, slot_mapping)
+    T, heads, head = key.shape
+    if key_cache.dim() != 4 or key_cache.shape[2] != heads or key_cache.shape[3] != head or key_cache.stride(3) != 1:
+        raise RuntimeError("reshape_and_cache_flash: key_cache must be [blocks, block_size, heads, head] with a contiguous last dim")
+    if key_cache.stride() != value_cache.stride() or key_cache.shape != value_cache.shape:
+        raise RuntimeError("reshape_and_cache_flash: key_cache and value_cache must share shape and strides")
+    if slot_mapping.dtype != torch.int64:
+        raise RuntimeError("reshape_and_cache_flash: slot_mapping must be int64")
+    fp8 = _is_fp8(kv_cache_dtype)
+    per_head = 0
+    if fp8:
+        if k_scale is None or v_scale is None or k_scale.shape != v_scale.shape or k_scale.numel() not in (1, heads):
+            raise RuntimeError("reshape_and_cache_flash: k_scale and v_scale must be of shape [1] or [num_heads]")
+        per_head = int(k_scale.numel() > 1)
+    check(_lib.lib().mi355q_reshape_and_cache_flash(
+        key.data_ptr(), value.data_ptr(), key.stride(0), value.stride(0), key_cache.data_ptr(), value_cache.data_ptr(),
+        slot_mapping.data_ptr(), slot_mapping.numel(), heads, head, key_cache.shape[1], key_cache.stride(0),
+        key_cache.stride(1), key_cache.stride(2), _dt(key), int(fp8), _ptr(k_scale), _ptr(v_scale), per_head, _stream()))
+
+
 def rope_and_cache(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                    head_size: int, cos_sin_cache: torch.Tensor, is_neox: bool, key_cache: torch.Tensor,
                    value_cache: torch.Tensor, slot_mapping: torch.Tensor, kv_cache_dtype: str, k_scale, v_scale) -> None:

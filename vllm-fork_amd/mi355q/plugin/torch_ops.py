@@ -36,6 +36,8 @@ def register_torch_ops() -> None:
     d("silu_and_mul(Tensor! result, Tensor input) -> ()")
     d("reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, Tensor slot_mapping, "
       "str kv_cache_dtype, Tensor k_scale, Tensor v_scale) -> ()")
+    d("reshape_and_cache_flash(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, Tensor slot_mapping, "
+      "str kv_cache_dtype, Tensor k_scale, Tensor v_scale) -> ()")
     d("paged_attention(Tensor! out, Tensor! exp_sums, Tensor! max_logits, Tensor! tmp_out, Tensor query, "
       "Tensor key_cache, Tensor value_cache, int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens, "
       "Tensor? query_start_loc, int block_size, int max_seq_len, Tensor? alibi_slopes, str kv_cache_dtype, "
@@ -87,6 +89,10 @@ def register_torch_ops() -> None:
     def _(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype, k_scale, v_scale):
         ops.reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype, k_scale, v_scale)
 
+    @impl(_lib, "reshape_and_cache_flash", "CUDA")
+    def _(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype, k_scale, v_scale):
+        ops.reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype, k_scale, v_scale)
+
     @impl(_lib, "paged_attention", "CUDA")
     def _(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
           seq_lens, query_start_loc, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, k_scale, v_scale):
@@ -99,7 +105,7 @@ def register_torch_ops() -> None:
         ops.apply_repetition_penalties(logits, prompt_mask, output_mask, repetition_penalties)
 
     for name in ("rms_norm", "fused_add_rms_norm", "rotary_embedding", "silu_and_mul", "reshape_and_cache",
-                 "paged_attention", "apply_repetition_penalties_"):
+                 "reshape_and_cache_flash", "paged_attention", "apply_repetition_penalties_"):
         register_fake(f"mi355q::{name}")(lambda *a, **k: None)
 
     @impl(_lib, "argmax", "CUDA")
