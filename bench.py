@@ -296,7 +296,7 @@ def time_allreduce_16k(dev, reps=200):
         s.wait_stream(torch.cuda.current_stream())
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(s):
-            with torch.cuda.graph(g, stream=s):
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):   # the group's watchdog thread keeps querying events
                 for _ in range(50):
                     torch.distributed.all_reduce(x)
             g.replay()

@@ -652,6 +652,17 @@ int mi355q_decode_attention_fused(
 int mi355q_argmax(const void* logits, int64_t row_stride, int64_t* ids, int num_rows, int vocab,
                   int dtype, mi355q_stream_t stream);
 
+/* mi355q_argmax plus what a greedy decode step does with the sampled id, in the same launch: positions[b] += 1,
+ * seq_lens[b] += 1 (either may be NULL) and hidden[b, :] = embedding[ids[b], :] (16-bit rows; both NULL: no
+ * gather) -- the next step's input, so that a captured step needs no separate increments or embedding lookup.
+ * The id must be a valid row of `embedding`.  No single reference counterpart: the reference runs
+ * logits.argmax (sampler.py:240-241), the model runner's position / sequence-length bookkeeping
+ * (gpu_model_runner.py:2001) and VocabParallelEmbedding as separate steps. */
+int mi355q_argmax_decode_step(const void* logits, int64_t row_stride, int64_t* ids, int num_rows, int vocab,
+                              int dtype, int64_t* positions, int32_t* seq_lens, const void* embedding,
+                              int64_t embedding_row_stride, void* hidden, int64_t hidden_row_stride,
+                              int hidden_size, mi355q_stream_t stream);
+
 /* Random sampling with top-k / top-p: ids[b] = argmax_i softmax(mask(logits[b] / temperature[b]))[i] / noise[b, i],
  * first index on ties.  mask keeps the top_k[b] largest logits (ties with the k-th kept; top_k NULL,
  * <= 0 or >= vocab: no top-k), then drops the longest ascending prefix whose cumulative probability

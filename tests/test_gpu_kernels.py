@@ -953,6 +953,39 @@ def test_sampler_golden(golden):
     np.testing.assert_allclose(lg.cpu().numpy(), g["penalized"], rtol=2e-7, atol=0)
 
 
+@pytest.mark.parametrize("V,narrow", [(128256, False), (32000, False), (2048, True)])
+def test_argmax_decode_step_advances_and_gathers(V, narrow):
+    """Arg-max with the decode step's bookkeeping in the same launch: ids as ops.argmax gives them, positions and
+    sequence lengths advanced by one, the sampled tokens' embedding rows gathered; wide (segmented) and narrow
+    arg-max paths, under a captured graph replayed twice."""
+    torch.manual_seed(V)
+    B, H = 5, 256
+    logits = torch.randn((B, V), device=DEV).to(torch.bfloat16)
+    logits[1, 7] = logits[1, V - 3] = 9.0            # a tie: the first index wins
+    embed = torch.randn((V, H), device=DEV).to(torch.bfloat16)
+    ids = torch.zeros(B, dtype=torch.int64, device=DEV)
+    pos = torch.arange(10, 10 + B, dtype=torch.int64, device=DEV)
+    sl = torch.arange(11, 11 + B, dtype=torch.int32, device=DEV)
+    hid = torch.zeros((B, H), dtype=torch.bfloat16, device=DEV)
+    want = ops.argmax(logits).clone()
+    assert int(want[1]) == 7 and torch.equal(want.cpu(), logits.float().argmax(-1).cpu())
+    ops.argmax_decode_step(logits, ids, pos, sl, embed, hid)
+    assert torch.equal(ids, want) and torch.equal(hid, embed[want])
+    assert pos.tolist() == list(range(11, 11 + B)) and sl.tolist() == list(range(12, 12 + B))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ops.argmax_decode_step(logits, ids, pos, sl, embed, hid)
+    logits[2, 5] = 50.0
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    assert int(ids[2]) == 5 and torch.equal(hid[2], embed[5])
+    assert pos.tolist() == list(range(13, 13 + B)) and sl.tolist() == list(range(14, 14 + B))   # one call and two replays
+    ops.argmax_decode_step(logits, ids, None, None)          # nothing but the arg-max
+    assert pos.tolist() == list(range(13, 13 + B))
+    with pytest.raises(RuntimeError, match="argmax_decode_step"):
+        ops.argmax_decode_step(logits, ids, pos.to(torch.int32), sl)
+
+
 def test_argmax_full_vocab_ties_and_strides():
     V = 128256
     rng = np.random.default_rng(0)

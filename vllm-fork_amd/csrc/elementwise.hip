@@ -707,12 +707,41 @@ int reset_argmax_state(hipStream_t stream) {
   return check_launch("argmax_reset_kernel");
 }
 
+// What a greedy decode step does with the sampled id besides storing it: advance the sequence's position and
+// length, and fetch the id's embedding row as the next step's first hidden state.  All pointers null: nothing.
+struct StepTail {
+  int64_t* positions;
+  int32_t* seq_lens;
+  const uint16_t* embed;
+  int64_t embed_stride;
+  uint16_t* hidden;
+  int64_t hidden_stride;
+  int hidden_size;   // 16-bit elements, a multiple of 8
+};
+
+__device__ inline void step_tail_row(const StepTail& t, int rowi, int64_t id) {   // the whole workgroup calls this
+  if (threadIdx.x == 0) {
+    if (t.positions) t.positions[rowi] += 1;
+    if (t.seq_lens) t.seq_lens[rowi] += 1;
+  }
+  if (t.embed && t.hidden) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(t.embed + (size_t)id * t.embed_stride);
+    u32x4* dst = reinterpret_cast<u32x4*>(t.hidden + (size_t)rowi * t.hidden_stride);
+    for (int v = threadIdx.x; v < t.hidden_size / 8; v += blockDim.x) dst[v] = src[v];
+  }
+}
+
+// the tail as a launch of its own: after the single-workgroup arg-max, one workgroup per row
+__global__ void step_tail_kernel(const int64_t* __restrict__ ids, StepTail t) { step_tail_row(t, blockIdx.x, ids[blockIdx.x]); }
+
 template <int DTID>
 __global__ __launch_bounds__(256) void argmax_wide_kernel(const void* __restrict__ logits, int64_t row_stride,
-                                                          int64_t* __restrict__ ids, int V, int segs, int bank) {
+                                                          int64_t* __restrict__ ids, int V, int segs, int bank,
+                                                          const StepTail tail) {
   constexpr int ES = DTID == MI355Q_FP32 ? 4 : 2, EPV = 16 / ES;
   typedef unsigned long long u64;
   __shared__ u64 skey[4];
+  __shared__ long long s_winner;
   const int rowi = blockIdx.x, seg = blockIdx.y;
   const char* row = reinterpret_cast<const char*>(logits) + (size_t)rowi * row_stride * ES;
   const int per = ((V + segs - 1) / segs + EPV - 1) / EPV * EPV;   // elements per segment, whole vectors
@@ -771,7 +800,15 @@ __global__ __launch_bounds__(256) void argmax_wide_kernel(const void* __restrict
       __hip_atomic_store(&g_argmax_cnt[slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int idx = 0x7fffffff - (int)(uint32_t)(k & 0xffffffffu);
       ids[rowi] = idx == 0x7fffffff ? 0 : idx;   // row of -inf / NaN: index 0
+      s_winner = idx == 0x7fffffff ? 0 : idx;
+    } else {
+      s_winner = -1;
     }
+  }
+  if (tail.positions || tail.seq_lens || tail.embed) {   // the workgroup that closed the row runs the step's tail
+    __syncthreads();
+    const long long id = s_winner;
+    if (id >= 0) step_tail_row(tail, rowi, id);
   }
 }
 
@@ -1088,8 +1125,8 @@ extern "C" int mi355q_convert_fp8(void* dst, const void* src, int64_t n, float s
   return check_launch("convert_fp8_kernel");
 }
 
-extern "C" int mi355q_argmax(const void* logits, int64_t row_stride, int64_t* ids, int num_rows,
-                             int vocab, int dtype, mi355q_stream_t stream) {
+static int argmax_with_tail(const void* logits, int64_t row_stride, int64_t* ids, int num_rows,
+                            int vocab, int dtype, const StepTail& tail, mi355q_stream_t stream) {
   if (num_rows == 0) return MI355Q_OK;
   MI355Q_REQUIRE(logits && ids && vocab > 0, "argmax: bad arguments");
   MI355Q_REQUIRE(dtype >= MI355Q_BF16 && dtype <= MI355Q_FP32, "argmax: bad dtype");
@@ -1103,11 +1140,11 @@ extern "C" int mi355q_argmax(const void* logits, int64_t row_stride, int64_t* id
   if (bank >= 0) {
     const dim3 grid(num_rows, segs);
     if (dtype == MI355Q_FP32)
-      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_FP32>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs, bank);
+      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_FP32>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs, bank, tail);
     else if (dtype == MI355Q_BF16)
-      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_BF16>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs, bank);
+      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_BF16>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs, bank, tail);
     else
-      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_FP16>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs, bank);
+      hipLaunchKernelGGL((argmax_wide_kernel<MI355Q_FP16>), grid, dim3(256), 0, s, logits, row_stride, ids, vocab, segs, bank, tail);
     return check_launch("argmax_wide_kernel");
   }
   if (dtype == MI355Q_FP32)
@@ -1116,7 +1153,32 @@ extern "C" int mi355q_argmax(const void* logits, int64_t row_stride, int64_t* id
     hipLaunchKernelGGL((argmax_kernel<MI355Q_BF16>), dim3(num_rows), dim3(1024), 0, s, logits, row_stride, ids, vocab);
   else
     hipLaunchKernelGGL((argmax_kernel<MI355Q_FP16>), dim3(num_rows), dim3(1024), 0, s, logits, row_stride, ids, vocab);
-  return check_launch("argmax_kernel");
+  if (int e = check_launch("argmax_kernel")) return e;
+  if (tail.positions || tail.seq_lens || tail.embed) {
+    hipLaunchKernelGGL(step_tail_kernel, dim3(num_rows), dim3(256), 0, s, ids, tail);
+    return check_launch("step_tail_kernel");
+  }
+  return MI355Q_OK;
+}
+
+extern "C" int mi355q_argmax(const void* logits, int64_t row_stride, int64_t* ids, int num_rows,
+                             int vocab, int dtype, mi355q_stream_t stream) {
+  const StepTail none{nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
+  return argmax_with_tail(logits, row_stride, ids, num_rows, vocab, dtype, none, stream);
+}
+
+extern "C" int mi355q_argmax_decode_step(const void* logits, int64_t row_stride, int64_t* ids, int num_rows, int vocab,
+                                         int dtype, int64_t* positions, int32_t* seq_lens, const void* embedding,
+                                         int64_t embedding_row_stride, void* hidden, int64_t hidden_row_stride,
+                                         int hidden_size, mi355q_stream_t stream) {
+  if (embedding || hidden) {
+    MI355Q_REQUIRE(embedding && hidden && hidden_size > 0 && hidden_size % 8 == 0 && embedding_row_stride % 8 == 0 &&
+                       hidden_row_stride % 8 == 0 && ((((uintptr_t)embedding | (uintptr_t)hidden)) & 15) == 0,
+                   "argmax_decode_step: embedding / hidden rows must be 16-byte aligned multiples of 8 elements");
+  }
+  const StepTail tail{positions, seq_lens, (const uint16_t*)embedding, embedding_row_stride, (uint16_t*)hidden,
+                      hidden_row_stride, hidden_size};
+  return argmax_with_tail(logits, row_stride, ids, num_rows, vocab, dtype, tail, stream);
 }
 
 extern "C" int mi355q_apply_repetition_penalties(void* logits, const uint8_t* prompt_mask,

@@ -115,6 +115,8 @@ _SIGS = {
                                               c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_int, c_int,
                                               c_int, c_int, c_vp, c_vp, c_vp]),
     "mi355q_argmax": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_vp]),
+    "mi355q_argmax_decode_step": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,
+                                          c_int, c_vp]),
     "mi355q_gptq_expand_bits": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_sample_topk_topp": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "mi355q_apply_repetition_penalties": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),

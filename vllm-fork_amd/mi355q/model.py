@@ -338,6 +338,10 @@ class LlamaRunner:
         self.exp_sums = torch.empty((B, self.heads, self.P), dtype=torch.float32, device=self.device)
         self.max_logits = torch.empty_like(self.exp_sums)
         self.graph = None
+        # the next decode step's first hidden state: the embedding row of the token sampled last, fetched by
+        # the step's last launch (ops.argmax_decode_step) together with the position / length increments
+        self.h0 = torch.zeros((B, cfg.hidden), dtype=dtype, device=self.device)
+        self.step_tail = os.environ.get("MI355Q_STEP_TAIL", "1") == "1" and dtype in (torch.bfloat16, torch.float16)
 
     # ------------------------------------------------------------------
     def weight_bytes(self) -> int:
@@ -510,6 +514,7 @@ class LlamaRunner:
         self.tokens[:B] = ids
         self.positions[:B] = T
         self.seq_lens[:B] = T + 1
+        self.h0[:B] = self.embed.index_select(0, ids)
         return ids
 
     def _decode_body(self):
@@ -526,21 +531,25 @@ class LlamaRunner:
                                          self.block_size, self.max_seq_len, None, self.kv_cache_dtype, self.k_scale,
                                          self.v_scale)
 
-        h = self.embed.index_select(0, self.tokens)
+        h = self.h0 if self.step_tail else self.embed.index_select(0, self.tokens)
         residual = None
         normed = False
         for li, L in enumerate(self.layers):
             h, residual, normed = self._layer(L, li, h, residual, self.positions, slot_mapping, attend, normed,
                                               self._next_norm(li))
-        ops.argmax(self._logits(h, residual, normed), out=self.tokens)
-        self.positions.add_(1)
-        self.seq_lens.add_(1)
+        logits = self._logits(h, residual, normed)
+        if self.step_tail:   # arg-max, position / length increments and the next step's embedding row in one launch
+            ops.argmax_decode_step(logits, self.tokens, self.positions, self.seq_lens, self.embed, self.h0)
+        else:
+            ops.argmax(logits, out=self.tokens)
+            self.positions.add_(1)
+            self.seq_lens.add_(1)
 
     def capture(self):
         """Capture the decode step into a HIP graph (the reference captures the whole model forward,
         v1/worker/gpu_model_runner.py:6834; every op here is capture-safe)."""
         # warm up on a side stream so allocator state and the split-K workspace exist before capture
-        state = (self.tokens.clone(), self.positions.clone(), self.seq_lens.clone())
+        state = (self.tokens.clone(), self.positions.clone(), self.seq_lens.clone(), self.h0.clone())
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -548,11 +557,14 @@ class LlamaRunner:
                 self._decode_body()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.tokens.copy_(state[0]); self.positions.copy_(state[1]); self.seq_lens.copy_(state[2])
+        self.tokens.copy_(state[0]); self.positions.copy_(state[1]); self.seq_lens.copy_(state[2]); self.h0.copy_(state[3])
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # with a process group alive its watchdog thread queries events while this thread captures: only this
+        # thread's calls may invalidate the capture (the default mode faults the whole process for them)
+        mode = "thread_local" if self.tp_collectives else "global"
+        with torch.cuda.graph(g, capture_error_mode=mode):
             self._decode_body()
-        self.tokens.copy_(state[0]); self.positions.copy_(state[1]); self.seq_lens.copy_(state[2])
+        self.tokens.copy_(state[0]); self.positions.copy_(state[1]); self.seq_lens.copy_(state[2]); self.h0.copy_(state[3])
         self.graph = g
 
     def decode_step(self):
@@ -566,3 +578,4 @@ class LlamaRunner:
         self.tokens.fill_(1)
         self.positions.fill_(ctx)
         self.seq_lens.fill_(ctx + 1)
+        self.h0.copy_(self.embed.index_select(0, self.tokens))

@@ -1118,6 +1118,36 @@ def argmax(logits: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tenso
     return ids
 
 
+def argmax_decode_step(logits: torch.Tensor, ids: torch.Tensor, positions: torch.Tensor | None, seq_lens: torch.Tensor | None,
+                       embedding: torch.Tensor | None = None, hidden: torch.Tensor | None = None) -> torch.Tensor:
+    """argmax into `ids` (int64 [rows]) and, in the same launch, positions += 1 (int64), seq_lens += 1 (int32) and
+    hidden[b] = embedding[ids[b]]: the bookkeeping of a greedy decode step (sampler.py:240-241 followed by the model
+    runner's position update and the next step's embedding lookup)."""
+    _need_cuda(logits, ids)
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("argmax_decode_step: logits must be [rows, vocab] with a contiguous last dim")
+    B = logits.shape[0]
+    if ids.dtype != torch.int64 or ids.shape != (B,) or not ids.is_contiguous():
+        raise RuntimeError("argmax_decode_step: ids must be a contiguous int64 tensor with one entry per row")
+    if positions is not None and (positions.dtype != torch.int64 or positions.shape != (B,) or not positions.is_contiguous()):
+        raise RuntimeError("argmax_decode_step: positions must be contiguous int64 [rows]")
+    if seq_lens is not None and (seq_lens.dtype != torch.int32 or seq_lens.shape != (B,) or not seq_lens.is_contiguous()):
+        raise RuntimeError("argmax_decode_step: seq_lens must be contiguous int32 [rows]")
+    H = 0
+    if embedding is not None or hidden is not None:
+        if embedding is None or hidden is None or embedding.dtype != hidden.dtype or embedding.dim() != 2 or \
+                hidden.shape != (B, embedding.shape[1]) or embedding.stride(1) != 1 or hidden.stride(1) != 1 or \
+                embedding.shape[0] < logits.shape[1] or embedding.element_size() != 2:
+            raise RuntimeError("argmax_decode_step: embedding [vocab, hidden] and hidden [rows, hidden] must be 16-bit, "
+                               "same dtype, contiguous rows, one embedding row per logit")
+        H = embedding.shape[1]
+    check(_lib.lib().mi355q_argmax_decode_step(
+        logits.data_ptr(), logits.stride(0), ids.data_ptr(), B, logits.shape[1], _dt(logits, True), _ptr(positions),
+        _ptr(seq_lens), _ptr(embedding), embedding.stride(0) if embedding is not None else 0, _ptr(hidden),
+        hidden.stride(0) if hidden is not None else 0, H, _stream()))
+    return ids
+
+
 def sample_topk_topp(logits: torch.Tensor, temperature: torch.Tensor | None, top_k: torch.Tensor | None,
                      top_p: torch.Tensor | None, noise: torch.Tensor) -> torch.Tensor:
     """argmax(softmax(top_k_top_p_mask(logits / temperature)) / noise) per row, without sorting the vocabulary.
