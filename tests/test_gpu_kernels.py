@@ -1055,8 +1055,20 @@ def test_w4a16_split_k_counters_are_left_clean():
 def test_decode_attention_fused_equals_unfused(H, KVH, D, bs, fp8):
     """One launch (RoPE + cache write + attention) == rotary_embedding, reshape_and_cache,
     paged_attention_rocm back to back: outputs and cache contents bit for bit."""
+    _fused_equals_unfused(H, KVH, D, bs, fp8, [1, 16, 130, 256, 257, 600])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_decode_attention_fused_equals_unfused_random_batches(seed):
+    """Batches of random context lengths (one to eight partitions, Llama-3-8B heads): bit for bit again.  The
+    kernels of this file repeat the same fp32 expressions and are built without implicit fused multiply-adds, so
+    that the compiler cannot contract an expression in one of them and not in the other."""
+    lens = [int(v) for v in np.random.default_rng(seed).integers(1, 2000, size=12)] + [512, 900, 1025]
+    _fused_equals_unfused(32, 8, 128, 16, seed == 1, lens)
+
+
+def _fused_equals_unfused(H, KVH, D, bs, fp8, lens):      # lens: seq_len including the new token
     rng = np.random.default_rng(H * D)
-    lens = [1, 16, 130, 256, 257, 600]          # seq_len including the new token
     S = len(lens)
     x = 16 if fp8 else 8
     nblk = S * ((max(lens) + bs - 1) // bs)
@@ -1078,7 +1090,7 @@ def test_decode_attention_fused_equals_unfused(H, KVH, D, bs, fp8):
         vc0 = torch.from_numpy(rng.uniform(-1, 1, (nblk, KVH, D, bs)).astype(np.float32)).to(torch.bfloat16).to(DEV)
     qkv = torch.from_numpy(rng.uniform(-1, 1, (S, (H + 2 * KVH) * D)).astype(np.float32)).to(torch.bfloat16).to(DEV)
     inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float) / D))
-    fr = torch.einsum("i,j->ij", torch.arange(1024, dtype=torch.float), inv)
+    fr = torch.einsum("i,j->ij", torch.arange(2048, dtype=torch.float), inv)
     cache = torch.cat((fr.cos(), fr.sin()), -1).to(torch.bfloat16).to(DEV)
     P = (max(lens) + 255) // 256
 

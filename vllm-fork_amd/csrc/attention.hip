@@ -19,6 +19,13 @@
 
 #include "common.h"
 
+// No fused multiply-add unless the source asks for one: the kernels below repeat the same fp32 expressions (one
+// workgroup per item, workgroups that walk several items, fused and unfused decode steps, in-kernel and separate
+// partition merges) and promise the same bits.  Left to itself the compiler contracts a * b + c in one of them
+// and not in another, depending on what surrounds the expression, and the results then differ in the last bit
+// now and then (seen: one output element in tens of thousands).
+#pragma clang fp contract(off)
+
 namespace mi355q {
 
 struct PAParams {
