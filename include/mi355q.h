@@ -449,6 +449,38 @@ int mi355q_fp8_scaled_mm(const void* a, int64_t lda, const void* w, int64_t ldw,
                          int scale_a_numel, const float* scale_b, int scale_b_numel, const void* bias, void* c,
                          int64_t ldc, int M, int N, int K, int out_dtype, mi355q_stream_t stream);
 
+/*
+ * Per-token-group fp8 quantisation, the activations of the block-scaled product below: for every token and
+ * every group of `group_size` consecutive elements, scale = max(eps, max |x|) / 448 and
+ * out = fp8_e4m3fn(clamp(x / scale, -448, 448)).  input: bf16 / fp16 / fp32 [num_tokens, hidden], hidden a
+ * multiple of group_size; the scale of (token t, group g) is written at scales[t * scale_stride_token +
+ * g * scale_stride_group], which serves the row-major [T, H / gs] tensor and its column-major form alike.
+ * Replaces per_token_group_quant_fp8 = torch.ops._C.per_token_group_fp8_quant
+ * (vllm/model_executor/layers/quantization/utils/fp8_utils.py:533-659,
+ * csrc/libtorch_stable/quantization/w8a8/fp8/per_token_group_quant.cu:40-160), without its ue8m0 scale rounding
+ * (a DeepGEMM option that is off on ROCm).
+ */
+int mi355q_per_token_group_fp8_quant(void* out, int64_t out_stride, const void* input, int64_t input_stride,
+                                     float* scales, int64_t scale_stride_token, int64_t scale_stride_group,
+                                     int num_tokens, int hidden, int group_size, float eps, int dtype,
+                                     mi355q_stream_t stream);
+/*
+ * Block-scaled fp8 product of DeepSeek-V3 / Qwen3 style checkpoints:
+ *   C[m, n] (out_dtype) = round(sum over 128-wide k blocks b of (A[m, b] . W[n, b]) * a_scales[m, b] *
+ *                         w_scales[n / block_n, b] + bias[n])
+ * A: fp8 [M, K] (row stride lda) with one fp32 scale per (token, 128-wide block); W: fp8 [N, K] (row stride
+ * ldw) with one fp32 scale per (block_n x block_k) tile; scale tensors are addressed through their strides.
+ * block_k must be 128, block_n a multiple of 16 (of 32 beyond 64 rows); K, lda, ldw multiples of 16; a
+ * ragged last block of K or N is allowed.  Every 128-wide block is accumulated on its own and folded into the
+ * fp32 sum as (dot * a_scale) * w_scale, the order of the reference kernel.  Replaces
+ * w8a8_triton_block_scaled_mm (fp8_utils.py:736-817,859-990) behind W8A8BlockFp8LinearOp.
+ */
+int mi355q_fp8_block_scaled_mm(const void* a, int64_t lda, const float* a_scales, int64_t a_scale_stride_token,
+                               int64_t a_scale_stride_block, const void* w, int64_t ldw, const float* w_scales,
+                               int64_t w_scale_stride_n, int64_t w_scale_stride_k, int block_n, int block_k,
+                               const void* bias, void* c, int64_t ldc, int M, int N, int K, int out_dtype,
+                               mi355q_stream_t stream);
+
 /* ------------------------------------------------------------------ */
 /* Unquantized skinny linear (lm_head, bf16 decode comparator)         */
 /* ------------------------------------------------------------------ */

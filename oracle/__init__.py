@@ -513,3 +513,26 @@ def fp8_scaled_mm(a, w, scale_a, scale_b, bias=None, dt=BF16):
     lib().orc_fp8_scaled_mm(_p(a), _p(w), _p(sa), _i(sa.size), _p(sb), _i(sb.size), _p(b), _p(c), _i(M), _i(N), _i(K),
                             _i(dt))
     return c
+
+
+def per_token_group_quant_fp8(x, group_size, eps=1e-10, dt=BF16):
+    """x: [T, H] (bit patterns, or fp32 for dt = FP32); returns (fp8 bytes [T, H], scales fp32 [T, H / group_size])."""
+    x = _in(x, dt)
+    T, H = x.shape
+    out, scales = np.empty((T, H), dtype=np.uint8), np.zeros((T, H // group_size), dtype=np.float32)
+    lib().orc_per_token_group_quant_fp8(_p(x), _i64(H), _p(scales), _p(out), _i(T), _i(H), _i(group_size), _f(eps), _i(dt))
+    return out, scales
+
+
+def w8a8_block_scaled_mm(a, b, a_scales, b_scales, block_size, dt=BF16, bias=None):
+    """a: fp8 bytes [M, K]; b: fp8 bytes [N, K]; a_scales fp32 [M, ceil(K / bk)]; b_scales fp32 [ceil(N / bn), ceil(K / bk)]."""
+    a, b = np.ascontiguousarray(a, dtype=np.uint8), np.ascontiguousarray(b, dtype=np.uint8)
+    (M, K), N = a.shape, b.shape[0]
+    sa = np.ascontiguousarray(a_scales, dtype=np.float32)
+    sb = np.ascontiguousarray(b_scales, dtype=np.float32)
+    bn, bk = block_size
+    assert sa.shape == (M, -(-K // bk)) and sb.shape == (-(-N // bn), -(-K // bk))
+    c = np.empty((M, N), dtype=np.uint16)
+    bb = None if bias is None else np.ascontiguousarray(bias, dtype=np.uint16)
+    lib().orc_w8a8_block_scaled_mm(_p(a), _p(b), _p(sa), _p(sb), _p(bb), _p(c), _i(M), _i(N), _i(K), _i(bn), _i(bk), _i(dt))
+    return c

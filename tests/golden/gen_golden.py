@@ -692,8 +692,35 @@ def gen_fp8_w8a8():
             out[tag + "_bias"] = bits16(bias)
         out[tag + "_ref"] = bits16(ref)
         out[tag + "_dt"] = np.array([0 if dtype == torch.bfloat16 else 1])
+    # per-token-group quantisation and the block-scaled product: the reference test's own restatements
+    # (tests/kernels/quant_utils.py:157-180 and :91-154, imported) on the inputs of
+    # tests/kernels/quantization/test_block_fp8.py:86-153 (sizes cut to what a fixture can hold)
+    pnames = []
+    for T, H, gs in [(7, 512, 64), (7, 512, 128), (7, 4096, 128), (3, 5120, 512), (33, 512, 128)]:
+        torch.manual_seed(0)
+        tag = f"ptg_{T}x{H}_{gs}"
+        x = torch.rand(T, H, dtype=torch.bfloat16)
+        q, sc = tq.native_per_token_group_quant_fp8(x, gs)
+        pnames.append(tag)
+        out[tag + "_x"], out[tag + "_gs"] = bits16(x), np.array([gs])
+        out[tag + "_q"], out[tag + "_s"] = bits8(q), sc.numpy()
+    bnames = []
+    for M_, N_, K_ in [(1, 128, 256), (7, 512, 256), (8, 576, 1024), (83, 128, 3884 // 4 * 4), (1, 576, 4096), (130, 512, 384)]:
+        torch.manual_seed(0)
+        tag = f"blockmm_{M_}x{N_}x{K_}"
+        fmax = 448.0
+        A8 = ((torch.rand(M_, K_, dtype=torch.float32) - 0.5) * 2 * fmax).clamp(min=-fmax, max=fmax).to(tq.FP8_DTYPE)
+        B8 = ((torch.rand(N_, K_, dtype=torch.float32) - 0.5) * 2 * fmax).clamp(min=-fmax, max=fmax).to(tq.FP8_DTYPE)
+        kt, nt = -(-K_ // 128), -(-N_ // 128)
+        As = torch.rand(M_, kt, dtype=torch.float32) * 1e-2
+        Bs = torch.rand(nt, kt, dtype=torch.float32) * 1e-2
+        ref = tq.native_w8a8_block_matmul(A8, B8, As, Bs, [128, 128], torch.bfloat16)
+        bnames.append(tag)
+        out[tag + "_a"], out[tag + "_b"] = bits8(A8), bits8(B8)
+        out[tag + "_as"], out[tag + "_bs"] = As.numpy(), Bs.numpy()
+        out[tag + "_ref"] = bits16(ref)
     save("fp8_w8a8", dyn_names=np.array(names), static_names=np.array(gnames), normq_names=np.array(nnames),
-         mm_names=np.array(mnames), **out)
+         mm_names=np.array(mnames), ptg_names=np.array(pnames), blockmm_names=np.array(bnames), **out)
 
 
 GENERATORS = {"pack": gen_pack, "quantize": gen_quantize, "w4a16": gen_w4a16, "awq": gen_awq, "rmsnorm": gen_rmsnorm,

@@ -336,3 +336,123 @@ def test_fp8_scaled_mm_errors():
     with pytest.raises(RuntimeError, match="float8_e4m3fn"):
         ops.fp8_scaled_mm(a.view(torch.uint8), w, torch.bfloat16, one, one)
     assert ops.fp8_scaled_mm(a[:0], w, torch.bfloat16, one, one).shape == (0, 8)
+
+
+# ---------------------------------------------------------------------------
+# block-scaled product: per-token-group activation scales x per-block weight scales
+# ---------------------------------------------------------------------------
+def test_per_token_group_quant_golden(golden):
+    """The reference test's restatement (tests/kernels/quant_utils.py:157-180) on its inputs: bytes and scales bit
+    for bit -- a maximum is the only reduction in front of them (the reference's own ROCm bar allows one e4m3 step on
+    0.05 % of the elements against its Triton kernel, test_block_fp8.py:96-110)."""
+    g = golden("fp8_w8a8")
+    for tag in g["ptg_names"]:
+        gs = int(g[tag + "_gs"][0])
+        q, sc = ops.per_token_group_quant_fp8(to_dev(g[tag + "_x"]), gs)
+        assert np.array_equal(sc.cpu().numpy(), g[tag + "_s"]), tag
+        assert np.array_equal(bits8(q), g[tag + "_q"]), tag
+        q2, sc2 = ops.per_token_group_quant_fp8(to_dev(g[tag + "_x"]), gs, column_major_scales=True)
+        assert sc2.stride(-2) == 1 and sc2.shape == sc.shape, tag
+        assert torch.equal(sc2.contiguous(), sc) and torch.equal(q2.view(torch.uint8), q.view(torch.uint8)), tag
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("T,H,gs", [(1, 128, 128), (7, 4096, 128), (2050, 512, 64), (5, 13824, 512), (3, 1024, 32), (9, 960, 24)])
+def test_per_token_group_quant_vs_oracle(T, H, gs, dtype):
+    """Every input dtype, group sizes of test_block_fp8.py:46-48 and two that take the element-wise form, an
+    all-zero group (scale = eps / 448), a row stride wider than the row."""
+    gen = torch.Generator().manual_seed(T + H + gs)
+    x = ((torch.rand(T, H + 64, generator=gen) - 0.3) * 8).to(dtype)
+    x[0, :gs] = 0
+    xs = x[:, :H]
+    want_q, want_s = orc.per_token_group_quant_fp8(host_bits(xs.contiguous()), gs, dt=odt(dtype))
+    q, sc = ops.per_token_group_quant_fp8(x.to(DEV)[:, :H], gs)
+    assert np.array_equal(sc.cpu().numpy(), want_s)
+    assert np.array_equal(bits8(q), want_q)
+    assert float(sc[0, 0]) == np.float32(1e-10) / np.float32(448.0)
+
+
+def test_block_scaled_mm_golden(golden):
+    """native_w8a8_block_matmul outputs (tests/kernels/quant_utils.py:91-154) on the inputs of test_block_fp8.py:125-153,
+    at that test's bar: mean |diff| / mean |ref| < 1e-3."""
+    g = golden("fp8_w8a8")
+    for tag in g["blockmm_names"]:
+        a, b = fp8_dev(g[tag + "_a"]), fp8_dev(g[tag + "_b"])
+        As, Bs = torch.from_numpy(g[tag + "_as"]).to(DEV), torch.from_numpy(g[tag + "_bs"]).to(DEV)
+        out = ops.w8a8_block_scaled_mm(a, b, As, Bs, [128, 128], torch.bfloat16)
+        got, ref = orc.h16_to_f32(bits16(out)), orc.h16_to_f32(g[tag + "_ref"])
+        assert np.abs(got - ref).mean() / np.abs(ref).mean() < 1e-3, tag
+        np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * float(np.abs(ref).max()), err_msg=tag)
+
+
+def _block_case(M, N, K, dt, bn=128, biased=False, seed=0):
+    g = torch.Generator().manual_seed(seed + M * 7 + N * 3 + K)
+    a = ((torch.rand(M, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(torch.float8_e4m3fn)
+    w = ((torch.rand(N, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(torch.float8_e4m3fn)
+    kt, nt = -(-K // 128), -(-N // bn)
+    As = (torch.rand(M, kt, generator=g) * 1e-2).float()
+    Bs = (torch.rand(nt, kt, generator=g) * 1e-2).float()
+    bias = (torch.rand(N, generator=g) * 2 - 1).to(TDT[dt]) if biased else None
+    want = orc.h16_to_f32(orc.w8a8_block_scaled_mm(bits8(a), bits8(w), As.numpy(), Bs.numpy(), [bn, 128], dt,
+                                                   None if bias is None else bits16(bias)), dt)
+    got = ops.w8a8_block_scaled_mm(a.to(DEV), w.to(DEV), As.to(DEV), Bs.to(DEV), [bn, 128], TDT[dt],
+                                   None if bias is None else bias.to(DEV))
+    return orc.h16_to_f32(bits16(got), dt), want
+
+
+@pytest.mark.parametrize("M", [1, 7, 8, 16, 17, 33, 64])
+@pytest.mark.parametrize("N,K", [(128, 256), (512, 4096), (576, 3884), (7168, 4096), (4608, 7168), (1040, 528)])
+def test_block_scaled_mm_decode_rows_vs_oracle(M, N, K):
+    """Up to 64 rows on the weight-streaming kernel (every R x T instantiation): the shapes of test_block_fp8.py:50-52
+    (K = 3884 goes through zero-padded copies), a ragged last block in N and K."""
+    if N * K > 20_000_000 and M not in (1, 16, 64):
+        pytest.skip("large shapes at three row counts")
+    got, want = _block_case(M, N, K, orc.BF16)
+    assert np.abs(got - want).mean() / np.abs(want).mean() < 1e-3
+    np.testing.assert_allclose(got, want, rtol=2e-2, atol=1e-2 * float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("dt", [orc.BF16, orc.FP16])
+@pytest.mark.parametrize("M,N,K,bn", [(65, 128, 128, 128), (83, 576, 4096, 128), (200, 1040, 528, 128), (513, 7168, 4096, 128),
+                                      (4096, 512, 3888, 128), (130, 512, 384, 64), (300, 4608, 7168, 128)])
+def test_block_scaled_mm_prompt_rows_vs_oracle(M, N, K, bn, dt):
+    """The tiled kernel: partial tiles in M and N, a ragged last scale block, 64-channel weight blocks, bias."""
+    if dt == orc.FP16 and M * N > 1_000_000:
+        pytest.skip("large shapes in one dtype")
+    got, want = _block_case(M, N, K, dt, bn=bn, biased=(M % 2 == 0))
+    assert np.abs(got - want).mean() / np.abs(want).mean() < 1e-3
+    np.testing.assert_allclose(got, want, rtol=2e-2, atol=1e-2 * float(np.abs(want).max()))
+
+
+def test_block_scaled_mm_equals_dequantised_product():
+    """Quantise a bf16 activation and weight the way a block-quantised checkpoint and W8A8BlockFp8LinearOp do, and
+    compare the product with the fp32 product of the dequantised operands (fp8_utils.py:886-910's upcast form)."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 5, 512, 1024
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g) * 0.05
+    wb = w.view(N // 128, 128, K // 128, 128)
+    ws = wb.abs().amax(dim=(1, 3)) / 448.0
+    wq = (wb / ws[:, None, :, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(N, K)
+    xq, xs = ops.per_token_group_quant_fp8(x.to(DEV), 128)
+    out = ops.w8a8_block_scaled_mm(xq, wq.to(DEV), xs, ws.to(DEV), [128, 128], torch.bfloat16)
+    deq_x = xq.float().cpu() * xs.cpu().repeat_interleave(128, dim=1)
+    deq_w = wq.float() * ws.repeat_interleave(128, dim=0).repeat_interleave(128, dim=1)
+    ref = deq_x @ deq_w.t()
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2 * float(ref.abs().max()))
+    # and the quantisation error itself stays where fp8 puts it
+    exact = x.float() @ w.t()
+    assert float((out.float().cpu() - exact).abs().mean() / exact.abs().mean()) < 0.05
+
+
+def test_block_scaled_mm_errors():
+    a = torch.zeros((4, 256), dtype=torch.float8_e4m3fn, device=DEV)
+    w = torch.zeros((128, 256), dtype=torch.float8_e4m3fn, device=DEV)
+    As, Bs = torch.ones((4, 2), device=DEV), torch.ones((1, 2), device=DEV)
+    with pytest.raises(RuntimeError, match="block_k"):
+        ops.w8a8_block_scaled_mm(a, w, torch.ones((4, 4), device=DEV), torch.ones((1, 4), device=DEV), [128, 64])
+    with pytest.raises(RuntimeError, match="scale shapes"):
+        ops.w8a8_block_scaled_mm(a, w, As, torch.ones((2, 2), device=DEV), [128, 128])
+    with pytest.raises(RuntimeError, match="divisible"):
+        ops.per_token_group_quant_fp8(torch.zeros((2, 100), dtype=torch.bfloat16, device=DEV), 64)
+    assert ops.w8a8_block_scaled_mm(a, w, As, Bs, [128, 128]).shape == (4, 128)

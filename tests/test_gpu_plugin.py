@@ -455,6 +455,36 @@ def test_fp8_weight_only_linear_method(block):
     assert (to_bits(got) == ref).mean() > 0.97
 
 
+@pytest.mark.parametrize("T", [3, 70])
+def test_fp8_block_w8a8_linear_method(T):
+    """A block-quantised fp8 checkpoint ([128, 128] weight blocks) in w8a8 mode, the reference's W8A8BlockFp8LinearOp:
+    activations quantised per (token, 128-wide group), every k block of the product scaled on its own.  Against the
+    oracle's restatement of both steps on the same bytes, on the decode kernel (3 rows) and the tiled one (70)."""
+    from mi355q.plugin import Fp8Config
+    rng = np.random.default_rng(23)
+    hidden, inter = 512, 768
+    cfg = Fp8Config(True, "dynamic", weight_block_size=[128, 128], linear_mode="w8a8")
+    with torch.device(DEV):
+        gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16,
+                                        quant_config=cfg, prefix="mlp.gate_up_proj", return_bias=False)
+    assert gu.quant_method.w8a8_block
+    ws, ss = [], []
+    for i in range(2):
+        w8 = orc.f32_to_e4m3((rng.standard_normal((inter, hidden)) * 30).astype(np.float32))
+        s = (0.001 + 0.002 * rng.random((inter // 128, hidden // 128))).astype(np.float32)
+        gu.weight_loader(gu.weight, torch.from_numpy(w8).view(torch.float8_e4m3fn), i)
+        gu.weight_loader(gu.weight_scale_inv, torch.from_numpy(s), i)
+        ws.append(w8)
+        ss.append(s)
+    gu.process_weights_after_loading()
+    x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    xq, xs = orc.per_token_group_quant_fp8(x, 128)
+    ref = orc.w8a8_block_scaled_mm(xq, np.concatenate(ws), xs, np.concatenate(ss), [128, 128])
+    got = gu(to_dev(x))
+    np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=1e-2 * float(np.abs(f32(ref)).max()))
+    assert (to_bits(got) == ref).mean() > 0.9
+
+
 @pytest.mark.parametrize("scheme", ["dynamic", "static"])
 def test_fp8_w8a8_linear_method(scheme):
     """The reference's ROCm route for per-tensor fp8 checkpoints: fused shards requantised to the largest

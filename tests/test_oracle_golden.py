@@ -337,3 +337,24 @@ def test_fp8_scaled_mm_matches_torch_scaled_mm(golden):
         bias = g[tag + "_bias"] if tag + "_bias" in g else None
         c = orc.fp8_scaled_mm(g[tag + "_a"], g[tag + "_b"], g[tag + "_sa"], g[tag + "_sb"], bias, dt)
         np.testing.assert_allclose(f32(c, dt), f32(g[tag + "_ref"], dt), atol=1e-3, rtol=1e-2, err_msg=tag)
+
+
+def test_fp8_per_token_group_quant_matches_the_reference_restatement(golden):
+    """native_per_token_group_quant_fp8 (tests/kernels/quant_utils.py:157-180, imported) on the inputs of
+    test_block_fp8.py:86-107: scales and bytes bit for bit (no reduction but a maximum in front of them)."""
+    g = golden("fp8_w8a8")
+    for tag in g["ptg_names"]:
+        q, sc = orc.per_token_group_quant_fp8(g[tag + "_x"], int(g[tag + "_gs"][0]))
+        assert np.array_equal(sc, g[tag + "_s"]), tag
+        assert np.array_equal(q, g[tag + "_q"]), tag
+
+
+def test_fp8_block_scaled_mm_matches_the_reference_restatement(golden):
+    """native_w8a8_block_matmul (tests/kernels/quant_utils.py:91-154, imported) on the inputs of
+    test_block_fp8.py:125-153, at that test's bar (mean |diff| / mean |ref| < 1e-3) and element by element."""
+    g = golden("fp8_w8a8")
+    for tag in g["blockmm_names"]:
+        c = f32(orc.w8a8_block_scaled_mm(g[tag + "_a"], g[tag + "_b"], g[tag + "_as"], g[tag + "_bs"], [128, 128]), orc.BF16)
+        ref = f32(g[tag + "_ref"], orc.BF16)
+        assert np.abs(c - ref).mean() / np.abs(ref).mean() < 1e-3, tag
+        np.testing.assert_allclose(c, ref, rtol=2e-2, atol=2e-2 * float(np.abs(ref).max()), err_msg=tag)

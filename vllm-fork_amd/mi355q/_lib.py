@@ -81,6 +81,10 @@ _SIGS = {
     "mi355q_silu_and_mul_quant": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "mi355q_fp8_scaled_mm": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_int,
                                      c_int, c_int, c_int, c_vp]),
+    "mi355q_per_token_group_fp8_quant": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_f32,
+                                                 c_int, c_vp]),
+    "mi355q_fp8_block_scaled_mm": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int,
+                                           c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_linear_skinny": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_rms_norm": (c_int, [c_vp, c_vp, c_i64, c_vp, c_f32, c_int, c_int, c_int, c_vp]),
     "mi355q_fused_add_rms_norm": (c_int, [c_vp, c_i64, c_vp, c_vp, c_f32, c_int, c_int, c_int, c_vp]),

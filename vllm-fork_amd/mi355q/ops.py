@@ -797,6 +797,85 @@ def fp8_scaled_mm(a: torch.Tensor, weight: torch.Tensor, out_dtype: torch.dtype,
     return out
 
 
+def per_token_group_quant_fp8(x: torch.Tensor, group_size: int, eps: float = 1e-10, dtype: torch.dtype | None = None,
+                              column_major_scales: bool = False, out_q: torch.Tensor | None = None,
+                              use_ue8m0: bool = False) -> tuple[torch.Tensor, torch.Tensor]:
+    """per_token_group_quant_fp8 (vllm/model_executor/layers/quantization/utils/fp8_utils.py:533-659): one fp32
+    scale per (token, group of `group_size` elements), scale = max(eps, max |x|) / 448, x_q = fp8(clamp(x / scale)).
+    Returns (x_q like x, scales x.shape[:-1] + (H / group_size,)); with column_major_scales the scale tensor has
+    that shape over column-major storage (stride 1 along the tokens), as the reference returns it."""
+    _need_cuda(x, out_q)
+    dtype = FP8_DTYPE if dtype is None else dtype
+    if dtype != FP8_DTYPE:
+        raise RuntimeError("per_token_group_quant_fp8: only float8_e4m3fn outputs are built")
+    if use_ue8m0:
+        raise RuntimeError("per_token_group_quant_fp8: power-of-two (ue8m0) scales are a DeepGEMM option, not built")
+    H = x.shape[-1]
+    if H % group_size:
+        raise RuntimeError(f"the last dimension of `x` {H} must be divisible by `group_size` {group_size}")
+    if x.stride(-1) != 1:
+        raise RuntimeError("`x` groups must be contiguous")
+    x2 = x.reshape(-1, H)
+    T, G = x2.shape[0], H // group_size
+    if out_q is not None and (out_q.shape != x.shape or out_q.dtype != FP8_DTYPE or not out_q.is_contiguous()):
+        raise RuntimeError("per_token_group_quant_fp8: out_q must be a contiguous float8_e4m3fn tensor of x's shape")
+    x_q = out_q if out_q is not None else torch.empty(x.shape, dtype=FP8_DTYPE, device=x.device)
+    if column_major_scales:
+        if x.dim() != 2:
+            raise RuntimeError("per_token_group_quant_fp8: column-major scales are built for 2-D inputs")
+        x_s = torch.empty((G, T), dtype=torch.float32, device=x.device).permute(-1, -2)
+        st, sg = 1, T
+    else:
+        x_s = torch.empty(x.shape[:-1] + (G,), dtype=torch.float32, device=x.device)
+        st, sg = G, 1
+    check(_lib.lib().mi355q_per_token_group_fp8_quant(x_q.data_ptr(), H, x2.data_ptr(), x2.stride(0), x_s.data_ptr(), st, sg,
+                                                      T, H, group_size, float(eps), _dt(x2, True), _stream()))
+    return x_q, x_s
+
+
+def w8a8_block_scaled_mm(A: torch.Tensor, B: torch.Tensor, As: torch.Tensor, Bs: torch.Tensor, block_size: list[int],
+                         output_dtype: torch.dtype = torch.bfloat16, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """w8a8_triton_block_scaled_mm (fp8_utils.py:859-990): A fp8 [..., K] with per-token-group scales As
+    [..., ceil(K / block_k)], B fp8 [N, K] with per-block scales Bs [ceil(N / block_n), ceil(K / block_k)];
+    returns (sum over k blocks of (A_b . B_b^T) * As_b * Bs_b) in output_dtype, shape [..., N]."""
+    _need_cuda(A, B, As, Bs, bias)
+    if len(block_size) != 2:
+        raise RuntimeError("w8a8_block_scaled_mm: block_size must be [block_n, block_k]")
+    block_n, block_k = int(block_size[0]), int(block_size[1])
+    if A.dtype != FP8_DTYPE or B.dtype != FP8_DTYPE:
+        raise RuntimeError("w8a8_block_scaled_mm: operands must be float8_e4m3fn")
+    if As.dtype != torch.float32 or Bs.dtype != torch.float32:
+        raise RuntimeError("w8a8_block_scaled_mm: scales must be fp32")
+    K = A.shape[-1]
+    if B.dim() != 2 or Bs.dim() != 2 or B.shape[1] != K:
+        raise RuntimeError("w8a8_block_scaled_mm: B must be [N, K] and Bs 2-D")
+    N = B.shape[0]
+    kt, nt = -(-K // block_k), -(-N // block_n)
+    if As.shape[:-1] != A.shape[:-1] or As.shape[-1] != kt or tuple(Bs.shape) != (nt, kt):
+        raise RuntimeError(f"w8a8_block_scaled_mm: scale shapes {tuple(As.shape)} / {tuple(Bs.shape)} do not match "
+                           f"A {tuple(A.shape)}, B {tuple(B.shape)} and blocks {block_size}")
+    if output_dtype not in _DT or (bias is not None and (bias.dtype != output_dtype or bias.numel() != N)):
+        raise RuntimeError("w8a8_block_scaled_mm: output must be bf16 or fp16, the bias of that dtype with N elements")
+    A2 = A.reshape(-1, K)
+    As2 = As.reshape(-1, kt)
+    if K % 16 or A2.stride(0) % 16 or B.stride(0) % 16:
+        # rows that do not start on 16-byte boundaries (the reference test's K = 3884; no checkpoint has such a
+        # layer): zero-padded copies up to the next multiple of 16 -- zeros add nothing to a block's dot product
+        # and the padding never opens a new scale block
+        pad = (-K) % 16
+        A2 = torch.nn.functional.pad(A2.view(torch.uint8), (0, pad)).view(FP8_DTYPE)
+        B = torch.nn.functional.pad(B.view(torch.uint8), (0, pad)).view(FP8_DTYPE)
+    _rows2d(A2, "w8a8_block_scaled_mm A")
+    _rows2d(B, "w8a8_block_scaled_mm B")
+    M = A2.shape[0]
+    out = torch.empty((M, N), dtype=output_dtype, device=A.device)
+    check(_lib.lib().mi355q_fp8_block_scaled_mm(A2.data_ptr(), A2.stride(0), As2.data_ptr(), As2.stride(0), As2.stride(1),
+                                                B.data_ptr(), B.stride(0), Bs.data_ptr(), Bs.stride(0), Bs.stride(1),
+                                                block_n, block_k, _ptr(bias), out.data_ptr(), N, M, N, A2.shape[1],
+                                                _DT[output_dtype], _stream()))
+    return out.reshape(A.shape[:-1] + (N,))
+
+
 def wvSplitKQ(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype, scale_a: torch.Tensor, scale_b: torch.Tensor,
               cu_count: int, bias: torch.Tensor | None = None) -> torch.Tensor:
     """ops.wvSplitKQ (vllm/_custom_ops.py:2213-…): `a` is the weight [N, K], `b` the activations [M, K],

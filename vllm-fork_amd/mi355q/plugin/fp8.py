@@ -15,8 +15,12 @@ MI355Q_FP8_LINEAR, else "w8a8"):
   w8a16  weight-only: out = x @ (fp8(W) * scale)^T with 16-bit activations, the arithmetic of the
          reference's dequantise-then-linear fallback (:433-454); the reference has no such kernel
          on ROCm (kernels/linear/__init__.py:405-407).  `input_scale` tensors are accepted and ignored.
-         Block-quantised checkpoints always run this way (their w8a8 form needs per-token-group
-         activation scales, which this build does not have).
+
+Block-quantised checkpoints (`weight_block_size` [block_n, block_k], scales in `weight_scale_inv`) in w8a8 mode
+run the reference's W8A8BlockFp8LinearOp (fp8_utils.py: per_token_group_quant_fp8 with groups of block_k, then
+w8a8_triton_block_scaled_mm): activations get one fp32 scale per (token, block_k-wide group) and every k block of
+the product is scaled on its own.  That path is built for block_k = 128 and block_n a multiple of 32; any other
+block shape, and w8a16 mode, run weight-only.
 
 16-bit checkpoints are quantised per tensor at load time (quantization/online/fp8.py
 `Fp8PerTensorOnlineLinearMethod`).
@@ -131,6 +135,8 @@ class Fp8LinearMethod(LinearMethodBase):
         self.weight_block_size = quant_config.weight_block_size
         self.block_quant = self.weight_block_size is not None
         self.w8a8 = quant_config.linear_mode == "w8a8" and not self.block_quant
+        self.w8a8_block = (quant_config.linear_mode == "w8a8" and self.block_quant and self.weight_block_size[1] == 128
+                           and self.weight_block_size[0] % 32 == 0)
         self.act_q_static = quant_config.activation_scheme == "static"
 
     def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
@@ -225,6 +231,13 @@ class Fp8LinearMethod(LinearMethodBase):
             xq, xs = ops.scaled_fp8_quant(x2, scale=layer.input_scale.data if self.act_q_static else None)
             out = ops.fp8_scaled_mm(xq, layer.weight.data, x.dtype, xs, layer.weight_scale.data, bias)
             return out.reshape(x.shape[:-1] + (out.shape[-1],))
+        if self.w8a8_block:
+            # W8A8BlockFp8LinearOp.apply: per-token-group activation scales, block-scaled product
+            x2 = x.reshape(-1, x.shape[-1])
+            xq, xs = ops.per_token_group_quant_fp8(x2, self.weight_block_size[1])
+            out = ops.w8a8_block_scaled_mm(xq, layer.weight.data, xs, layer.weight_scale_inv.data,
+                                           list(self.weight_block_size), x.dtype, bias)
+            return out.reshape(x.shape[:-1] + (out.shape[-1],))
         scales = layer.weight_scale_inv if self.block_quant else layer.weight_scale
         return ops.w8a16_gemm(x, layer.weight.data.view(torch.uint8), scales.data, layer.mi355q_scale_block, bias)
 
@@ -233,7 +246,7 @@ class Fp8PerTensorOnlineLinearMethod(Fp8LinearMethod):
     """16-bit checkpoint, quantised at load: scale = max|W| / 448, W8 = fp8(W / scale)."""
 
     def __init__(self, quant_config: Fp8Config | None = None):
-        self.quant_config, self.weight_block_size, self.block_quant = quant_config, None, False
+        self.quant_config, self.weight_block_size, self.block_quant, self.w8a8_block = quant_config, None, False, False
         self.w8a8 = quant_config is not None and quant_config.linear_mode == "w8a8"
         self.act_q_static = False   # no calibrated input scale exists for a 16-bit checkpoint
 
