@@ -135,6 +135,173 @@ __global__ __launch_bounds__(512) void persist_k(const PLayer L) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// The persistent layer once more, with the hand-off and loader forms that cost least on this chip:
+//   * one LOADER wave per CU streams the weights of every stage, one after the other and without regard to the
+//     hand-offs, into a ring of 8 x 16 KiB LDS slots by LDS-DMA (16 x 1 KiB non-temporal loads per slot), three
+//     fills in flight; a slot is published (FULL word in LDS) once a counted vmcnt says it has landed and reused
+//     once its three consumers have released it (FREE word);
+//   * three CONSUMER waves per CU reduce the slots (here: xor) -- the stand-in for the dequantise + MFMA work;
+//   * the stage's result of a workgroup is ONE 8-byte granule {data, tag} written with a single write-through
+//     store; the next stage's input is gathered by one consumer wave per CU that sweeps all granules with
+//     write-through loads until every tag is the expected one (no counter, no fence, no second round trip);
+//   * while its CU gathers, the loader keeps a single fill outstanding.
+// One workgroup of 256 threads per CU (the ring pins it), one launch per layer.
+// ---------------------------------------------------------------------------
+struct EStage { const u32x4* w; int wgs, base_slots, extra; };   // workgroup b streams base_slots + (b < extra) slots
+struct ELayer {
+  EStage st[5];
+  const unsigned long long* g_in;   // granules of the previous layer's last stage (null: none)
+  int g_in_count;
+  unsigned g_in_tag;
+  unsigned long long* g_out;        // [5][256] granules of this layer
+  unsigned tag0;                    // stage s publishes tag0 + s
+  unsigned* err;
+  unsigned long long spin_limit;
+  int no_handoff;                   // diagnostics: consumers do not wait for their input (streaming rate of the ring alone)
+};
+
+#ifndef UB_INFLIGHT
+#define UB_INFLIGHT 3
+#endif
+#ifndef UB_AUX
+#define UB_AUX 2
+#endif
+constexpr int E_SLOTS = 8, E_SLOT_BYTES = 16384, E_INFLIGHT = UB_INFLIGHT;
+
+__global__ __launch_bounds__(256) void engine_k(const ELayer L) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];   // E_SLOTS x 16 KiB
+  __shared__ unsigned s_full[E_SLOTS], s_free[E_SLOTS];
+  __shared__ unsigned s_x[256], s_red[4], s_done[5], s_ready[5], s_gather, s_abort;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  if (threadIdx.x < E_SLOTS) { s_full[threadIdx.x] = 0; s_free[threadIdx.x] = 0; }
+  if (threadIdx.x < 5) { s_done[threadIdx.x] = 0; s_ready[threadIdx.x] = 0; }
+  if (threadIdx.x == 0) { s_gather = 0; s_abort = 0; }
+  __syncthreads();
+  volatile unsigned* v_full = s_full;
+  volatile unsigned* v_free = s_free;
+  volatile unsigned* v_done = s_done;
+  volatile unsigned* v_ready = s_ready;
+  volatile unsigned* v_gather = &s_gather;
+  volatile unsigned* v_abort = &s_abort;
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  auto expired = [&]() {
+    if (*v_abort) return true;
+    if (__builtin_amdgcn_s_memrealtime() - t_start > L.spin_limit) { *v_abort = 1; *L.err = 1; return true; }
+    return false;
+  };
+
+  if (wave == 0) {
+    // ---- loader ---------------------------------------------------------------------------------------------
+    unsigned q = 0;          // slots issued so far by this workgroup
+    unsigned published = 0;  // slots published so far
+    for (int s = 0; s < 5; s++) {
+      const EStage st = L.st[s];
+      if (b >= st.wgs) continue;
+      const int slots = st.base_slots + (b < st.extra ? 1 : 0);
+      const size_t first = (size_t)b * st.base_slots + (b < st.extra ? b : st.extra);
+      const u32x4* src = st.w + first * (E_SLOT_BYTES / 16) + lane;
+      for (int i = 0; i < slots; i++, q++) {
+        const unsigned slot = q % E_SLOTS, round = q / E_SLOTS;
+        // the slot's previous contents must have been released by all three consumers
+        while (v_free[slot] < 3 * round) { __builtin_amdgcn_s_sleep(1); if (expired()) return; }
+        unsigned char* dst = ring + (size_t)slot * E_SLOT_BYTES;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)i * 1024 + r * 64),
+                                           (void __attribute__((address_space(3)))*)(dst + r * 1024), 16, 0, UB_AUX);
+        // publish what has certainly landed: all but the newest fills
+        if (*v_gather) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          while (published <= q) { v_full[published % E_SLOTS] = published / E_SLOTS + 1; published++; }
+        } else if (q + 1 >= E_INFLIGHT) {
+          // 16 loads per fill: all but the newest E_INFLIGHT - 1 fills have landed
+          if constexpr (E_INFLIGHT == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else if constexpr (E_INFLIGHT == 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+          while (published + (E_INFLIGHT - 1) <= q) { v_full[published % E_SLOTS] = published / E_SLOTS + 1; published++; }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    while (published < q) { v_full[published % E_SLOTS] = published / E_SLOTS + 1; published++; }
+    return;
+  }
+
+  // ---- consumers ----------------------------------------------------------------------------------------------
+  const int c = wave - 1;
+  unsigned q = 0;
+  for (int s = 0; s < 5; s++) {
+    const EStage st = L.st[s];
+    if (b >= st.wgs) continue;
+    // input of the stage: the granules of the stage before (of the previous launch for stage 0)
+    const unsigned long long* gin = L.no_handoff ? nullptr : (s == 0 ? L.g_in : L.g_out + 256 * (s - 1));
+    const int gcount = s == 0 ? L.g_in_count : L.st[s - 1].wgs;
+    const unsigned gtag = s == 0 ? L.g_in_tag : L.tag0 + s - 1;
+    if (c == 0) {
+      unsigned d[4] = {0, 0, 0, 0};
+      if (gin) {
+        *v_gather = 1;
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int gi = lane + 64 * j;
+            const unsigned long long g = __hip_atomic_load(gin + (gi < gcount ? gi : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d[j] = gi < gcount ? (unsigned)g : 0u;
+            ok = ok && (unsigned)(g >> 32) == gtag;
+          }
+          if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (expired()) break;
+        }
+        *v_gather = 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) s_x[lane + 64 * j] = d[j];
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // the LDS writes above are done (lgkmcnt(0))
+      if (lane == 0) v_ready[s] = 1;
+    } else {
+      while (v_ready[s] == 0) { __builtin_amdgcn_s_sleep(1); if (expired()) break; }
+    }
+    unsigned acc = c == 0 ? (s_x[lane] ^ s_x[lane + 64] ^ s_x[lane + 128] ^ s_x[lane + 192]) : 0u;
+    const int slots = st.base_slots + (b < st.extra ? 1 : 0);
+    for (int i = 0; i < slots; i++, q++) {
+      const unsigned slot = q % E_SLOTS, round = q / E_SLOTS;
+      while (v_full[slot] < round + 1) { __builtin_amdgcn_s_sleep(1); if (expired()) break; }
+      const u32x4* src = reinterpret_cast<const u32x4*>(ring + (size_t)slot * E_SLOT_BYTES) + lane;
+      u32x4 v[6];
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        const int row = c + 3 * r;
+        v[r] = row < 16 ? src[row * 64] : u32x4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int r = 0; r < 6; r++) acc ^= v[r][0] ^ v[r][1] ^ v[r][2] ^ v[r][3];
+      asm volatile("" :: "v"(acc) : "memory");   // the slot's words are in registers before it is released
+      if (lane == 0) atomicAdd(&s_free[slot], 1u);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc ^= __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      s_red[c] = acc;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      atomicAdd(&s_done[s], 1u);
+    }
+    if (c == 0) {
+      while (v_done[s] < 3) { __builtin_amdgcn_s_sleep(1); if (expired()) break; }
+      if (lane == 0) {
+        const unsigned t = ((volatile unsigned*)s_red)[0] ^ ((volatile unsigned*)s_red)[1] ^ ((volatile unsigned*)s_red)[2];
+        const unsigned long long g = ((unsigned long long)(L.tag0 + s) << 32) | t;
+        __hip_atomic_store(L.g_out + 256 * s + b, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one write-through store
+      }
+    }
+    // s_red is reused by the next stage: consumers 1 and 2 wait for that stage's ready word first, which consumer 0
+    // sets after it has read s_red and published
+  }
+}
+
 struct Stage { double mb; int wgs; };
 
 // mode 0: one stream, no counters (stream order carries the dependency)
@@ -236,6 +403,55 @@ static float run_persist(hipStream_t sa, const u32x4* weights, size_t total_vecs
   return ms * 1000.f / (reps * layers);
 }
 
+static float run_engine(hipStream_t sa, const u32x4* weights, size_t total_vecs, unsigned long long* gran, unsigned* err,
+                        const std::vector<Stage>& stages, int layers, double* checksum, int no_handoff = 0) {
+  hipGraph_t g; hipGraphExec_t ge;
+  const size_t lds = (size_t)E_SLOTS * E_SLOT_BYTES;
+  if (hipFuncSetAttribute((const void*)engine_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { printf("lds attr failed\n"); return -1.f; }
+  hipStreamBeginCapture(sa, hipStreamCaptureModeGlobal);
+  hipMemsetAsync(gran, 0, sizeof(unsigned long long) * 5 * 256 * layers, sa);
+  size_t off = 0;
+  for (int l = 0; l < layers; l++) {
+    ELayer L;
+    int maxw = 0;
+    for (int k = 0; k < 5; k++) {
+      const long total_slots = (long)(stages[k].mb * 1e6 / E_SLOT_BYTES + 0.5);
+      const int wgs = stages[k].wgs;
+      const size_t vecs = (size_t)total_slots * (E_SLOT_BYTES / 16);
+      if (off + vecs > total_vecs) off = 0;
+      L.st[k] = EStage{weights + off, wgs, (int)(total_slots / wgs), (int)(total_slots % wgs)};
+      off += vecs;
+      maxw = wgs > maxw ? wgs : maxw;
+    }
+    L.g_in = l ? gran + (size_t)(l - 1) * 5 * 256 + 4 * 256 : nullptr;
+    L.g_in_count = stages[4].wgs;
+    L.g_in_tag = l ? (unsigned)(8 * (l - 1) + 1 + 4) : 0u;
+    L.g_out = gran + (size_t)l * 5 * 256;
+    L.tag0 = (unsigned)(8 * l + 1);
+    L.err = err;
+    L.spin_limit = 100ull * 20000ull;   // 20 ms
+    L.no_handoff = no_handoff;
+    hipLaunchKernelGGL(engine_k, dim3(maxw), dim3(256), lds, sa, L);
+  }
+  hipStreamEndCapture(sa, &g);
+  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { printf("instantiate failed\n"); return -1.f; }
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 2; i++) hipGraphLaunch(ge, sa);
+  hipStreamSynchronize(sa);
+  hipEventRecord(a, sa);
+  const int reps = 5;
+  for (int i = 0; i < reps; i++) hipGraphLaunch(ge, sa);
+  hipEventRecord(b, sa);
+  hipStreamSynchronize(sa);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  std::vector<unsigned long long> h((size_t)5 * 256 * layers);
+  hipMemcpy(h.data(), gran, h.size() * 8, hipMemcpyDeviceToHost);
+  double cs = 0; for (size_t i = 0; i < h.size(); i++) cs += (double)(unsigned)h[i] * ((i % 4096) + 1.0);
+  *checksum = cs;
+  hipGraphExecDestroy(ge); hipGraphDestroy(g);
+  return ms * 1000.f / (reps * layers);
+}
+
 int main() {
   hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
   const size_t bytes = (size_t)3600 << 20;
@@ -277,5 +493,18 @@ int main() {
   RUNP(4);
   RUNP(8);
   RUNP(14);
+  {
+    unsigned long long* gran; CK(hipMalloc(&gran, sizeof(unsigned long long) * 5 * 256 * layers));
+    double cs, cs2;
+    float t = run_engine(sa, w, total_vecs, gran, err, layer, layers, &cs);
+    unsigned ran_out = 0; CK(hipMemcpy(&ran_out, err, 4, hipMemcpyDeviceToHost));
+    printf("LDS-DMA ring (1 loader + 3 consumer waves per CU), 8-byte tagged granules, one launch per layer  layer %6.2f us  checksum %.0f  wait-ran-out %u\n", t, cs, ran_out);
+    fflush(stdout);
+    if (ran_out) _exit(2);
+    t = run_engine(sa, w, total_vecs, gran, err, layer, layers, &cs2);
+    printf("  again: layer %6.2f us  checksum %s\n", t, cs2 == cs ? "equal" : "DIFFERENT");
+    t = run_engine(sa, w, total_vecs, gran, err, layer, layers, &cs2, 1);
+    printf("  the ring alone (consumers do not wait for their inputs): layer %6.2f us\n", t);
+  }
   return 0;
 }
