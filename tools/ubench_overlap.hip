@@ -302,6 +302,119 @@ __global__ __launch_bounds__(256) void engine_k(const ELayer L) {
   }
 }
 
+// persist_k with the tagged-granule hand-off instead of arrival counters: every wave streams through its register
+// ring as there, workgroup outputs are 8-byte {data, tag} granules, wave 0 sweeps the previous stage's granules.
+struct GLayer { PStage st[5]; int out_g[5]; /* granules a stage publishes in all (0: one per workgroup) */ const unsigned long long* g_in; int g_in_count; unsigned g_in_tag; unsigned long long* g_out; unsigned tag0;
+                unsigned* err; unsigned long long spin_limit; };
+
+template <int DEPTH>
+__global__ __launch_bounds__(512) void persist_granule_k(const GLayer L) {
+  extern __shared__ unsigned pin_lds[];
+  __shared__ unsigned red[16];
+  __shared__ unsigned s_x[256];
+  __shared__ unsigned s_big[7168];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int s = 0; s < 5; s++) {
+    const PStage st = L.st[s];
+    const bool active = (int)blockIdx.x < st.wgs;
+    if (!active) continue;      // nobody waits for a workgroup that produces nothing
+    const long per_wave = st.vecs_per_wg / nw;
+    const u32x4* p = st.w + (long)blockIdx.x * st.vecs_per_wg + (long)wave * per_wave + lane;
+    const long steps = per_wave / 64;
+    u32x4 buf[DEPTH];
+#pragma unroll
+    for (int i = 0; i < DEPTH; i++) buf[i] = __builtin_nontemporal_load(p + (long)(i < steps ? i : 0) * 64);
+    const unsigned long long* gin = s == 0 ? L.g_in : L.g_out + (L.out_g[0] > 0 ? 7168 : 256) * (s - 1);
+    const int gcount = s == 0 ? L.g_in_count : L.st[s - 1].wgs;
+    const unsigned gtag = s == 0 ? L.g_in_tag : L.tag0 + s - 1;
+    if (L.out_g[0] > 0) {
+      // payloads of real size: every thread sweeps its share of the previous stage's granules until their tags match
+      const int total = gin ? (s == 0 ? L.out_g[4] : L.out_g[s - 1]) : 0;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (int base = 0; base < total; base += 512 * 4) {
+        unsigned long long g[4];
+        bool ok = false;
+        while (!ok) {
+          ok = true;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int gi = base + threadIdx.x + 512 * j;
+            g[j] = __hip_atomic_load(gin + (gi < total ? gi : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (unsigned)(g[j] >> 32) == gtag;
+          }
+          if (!ok) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > L.spin_limit) { *L.err = 1; break; }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int gi = base + threadIdx.x + 512 * j;
+          if (gi < total) s_big[gi] = (unsigned)g[j];
+        }
+      }
+      if (!gin && threadIdx.x < 256) s_big[threadIdx.x] = 0;
+      __syncthreads();
+      if (threadIdx.x < 256) {
+        unsigned v = 0;
+        for (int i = threadIdx.x; i < (total ? total : 256); i += 256) v ^= s_big[i];
+        s_x[threadIdx.x] = v;
+      }
+    } else
+    if (wave == 0) {
+      unsigned d[4] = {0, 0, 0, 0};
+      if (gin) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int gi = lane + 64 * j;
+            const unsigned long long g = __hip_atomic_load(gin + (gi < gcount ? gi : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d[j] = gi < gcount ? (unsigned)g : 0u;
+            ok = ok && (unsigned)(g >> 32) == gtag;
+          }
+          if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > L.spin_limit) { *L.err = 1; break; }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) s_x[lane + 64 * j] = d[j];
+    }
+    __syncthreads();
+    unsigned acc = s_x[lane] ^ s_x[lane + 64] ^ s_x[lane + 128] ^ s_x[lane + 192];
+    for (long k = 0; k < steps; k += DEPTH) {
+#pragma unroll
+      for (int i = 0; i < DEPTH; i++) {
+        u32x4 v = buf[i];
+        if (k + i < steps) acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+        if (k + DEPTH + i < steps) buf[i] = __builtin_nontemporal_load(p + (k + DEPTH + i) * 64);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc ^= __shfl_xor(acc, o, 64);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned t = 0;
+      for (int i = 0; i < nw; i++) t ^= red[i];
+      if (L.out_g[0] == 0)
+        __hip_atomic_store(L.g_out + 256 * s + blockIdx.x, ((unsigned long long)(L.tag0 + s) << 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      red[0] = t;
+    }
+    __syncthreads();
+    if (L.out_g[0] > 0) {
+      const int per = L.out_g[s] / st.wgs;     // this workgroup's share of the stage's output
+      if ((int)threadIdx.x < per)
+        __hip_atomic_store(L.g_out + 7168 * s + (size_t)blockIdx.x * per + threadIdx.x,
+                           ((unsigned long long)(L.tag0 + s) << 32) | (red[0] + threadIdx.x * 2654435761u), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();   // red and s_x are reused by the next stage
+  }
+}
+
 struct Stage { double mb; int wgs; };
 
 // mode 0: one stream, no counters (stream order carries the dependency)
@@ -403,6 +516,57 @@ static float run_persist(hipStream_t sa, const u32x4* weights, size_t total_vecs
   return ms * 1000.f / (reps * layers);
 }
 
+template <int DEPTH>
+static float run_persist_granule(hipStream_t sa, const u32x4* weights, size_t total_vecs, unsigned long long* gran, unsigned* err,
+                                 const std::vector<Stage>& stages, int layers, double* checksum, bool real = false) {
+  // outputs of real size, in granules of two 16-bit values: qkv 6144, attention 4096, o 4096, gate_up (after SiLU) 14336, down 4096
+  const int real_g[5] = {3072, 2048, 2048, 7168, 2048};
+  const size_t lstride = real ? 5 * 7168 : 5 * 256;
+  hipGraph_t g; hipGraphExec_t ge;
+  hipFuncSetAttribute((const void*)persist_granule_k<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  hipStreamBeginCapture(sa, hipStreamCaptureModeGlobal);
+  hipMemsetAsync(gran, 0, sizeof(unsigned long long) * lstride * layers, sa);
+  size_t off = 0;
+  for (int l = 0; l < layers; l++) {
+    GLayer L;
+    for (int k = 0; k < 5; k++) L.out_g[k] = real ? real_g[k] : 0;
+    int maxw = 0;
+    for (int k = 0; k < 5; k++) {
+      long vpw = (long)(stages[k].mb * 1e6 / 16 / stages[k].wgs) / (8 * 64) * (8 * 64);
+      if (vpw == 0) vpw = 8 * 64;
+      if (off + (size_t)vpw * stages[k].wgs > total_vecs) off = 0;
+      L.st[k] = PStage{weights + off, vpw, stages[k].wgs};
+      off += (size_t)vpw * stages[k].wgs;
+      maxw = stages[k].wgs > maxw ? stages[k].wgs : maxw;
+    }
+    L.g_in = l ? gran + (size_t)(l - 1) * lstride + 4 * (real ? 7168 : 256) : nullptr;
+    L.g_in_count = stages[4].wgs;
+    L.g_in_tag = l ? (unsigned)(8 * (l - 1) + 1 + 4) : 0u;
+    L.g_out = gran + (size_t)l * lstride;
+    L.tag0 = (unsigned)(8 * l + 1);
+    L.err = err;
+    L.spin_limit = 100ull * 20000ull;
+    hipLaunchKernelGGL((persist_granule_k<DEPTH>), dim3(maxw), dim3(512), 96 * 1024, sa, L);
+  }
+  hipStreamEndCapture(sa, &g);
+  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { printf("instantiate failed\n"); return -1.f; }
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 2; i++) hipGraphLaunch(ge, sa);
+  hipStreamSynchronize(sa);
+  hipEventRecord(a, sa);
+  const int reps = 5;
+  for (int i = 0; i < reps; i++) hipGraphLaunch(ge, sa);
+  hipEventRecord(b, sa);
+  hipStreamSynchronize(sa);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  std::vector<unsigned long long> h(lstride * layers);
+  hipMemcpy(h.data(), gran, h.size() * 8, hipMemcpyDeviceToHost);
+  double cs = 0; for (size_t i = 0; i < h.size(); i++) cs += (double)(unsigned)h[i] * ((i % 4096) + 1.0);
+  *checksum = cs;
+  hipGraphExecDestroy(ge); hipGraphDestroy(g);
+  return ms * 1000.f / (reps * layers);
+}
+
 static float run_engine(hipStream_t sa, const u32x4* weights, size_t total_vecs, unsigned long long* gran, unsigned* err,
                         const std::vector<Stage>& stages, int layers, double* checksum, int no_handoff = 0) {
   hipGraph_t g; hipGraphExec_t ge;
@@ -494,7 +658,7 @@ int main() {
   RUNP(8);
   RUNP(14);
   {
-    unsigned long long* gran; CK(hipMalloc(&gran, sizeof(unsigned long long) * 5 * 256 * layers));
+    unsigned long long* gran; CK(hipMalloc(&gran, sizeof(unsigned long long) * 5 * 7168 * layers));
     double cs, cs2;
     float t = run_engine(sa, w, total_vecs, gran, err, layer, layers, &cs);
     unsigned ran_out = 0; CK(hipMemcpy(&ran_out, err, 4, hipMemcpyDeviceToHost));
@@ -503,6 +667,29 @@ int main() {
     if (ran_out) _exit(2);
     t = run_engine(sa, w, total_vecs, gran, err, layer, layers, &cs2);
     printf("  again: layer %6.2f us  checksum %s\n", t, cs2 == cs ? "equal" : "DIFFERENT");
+#define RUNG(D)                                                                                                      \
+    {                                                                                                                \
+      double c3;                                                                                                     \
+      float tg = run_persist_granule<D>(sa, w, total_vecs, gran, err, layer, layers, &c3);                            \
+      CK(hipMemcpy(&ran_out, err, 4, hipMemcpyDeviceToHost));                                                         \
+      printf("depth %2d  one persistent kernel per layer, register rings, tagged granules  layer %6.2f us  checksum %.0f  wait-ran-out %u\n", D, tg, c3, ran_out); \
+      fflush(stdout);                                                                                                \
+      if (ran_out) _exit(2);                                                                                         \
+    }
+    RUNG(4);
+    RUNG(8);
+    RUNG(14);
+#define RUNGR(D)                                                                                                     \
+    {                                                                                                                \
+      double c3;                                                                                                     \
+      float tg = run_persist_granule<D>(sa, w, total_vecs, gran, err, layer, layers, &c3, true);                      \
+      CK(hipMemcpy(&ran_out, err, 4, hipMemcpyDeviceToHost));                                                         \
+      printf("depth %2d  the same with stage outputs of real size (24 / 16 / 16 / 57 / 16 KB of granules, every workgroup sweeps all)  layer %6.2f us  checksum %.0f  wait-ran-out %u\n", D, tg, c3, ran_out); \
+      fflush(stdout);                                                                                                \
+      if (ran_out) _exit(2);                                                                                         \
+    }
+    RUNGR(4);
+    RUNGR(14);
     t = run_engine(sa, w, total_vecs, gran, err, layer, layers, &cs2, 1);
     printf("  the ring alone (consumers do not wait for their inputs): layer %6.2f us\n", t);
   }
