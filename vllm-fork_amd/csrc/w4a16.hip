@@ -2429,6 +2429,10 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw, bool grouped = false) 
   // consumers (residual add + RMSNorm, RoPE + cache write), the whole pass measured slower with them
   // (TTFT(128) 5.36 -> 5.56 ms), so the wide forms stay the default.
   int spw = ns == 1 ? 4 : (ns == 2 ? 2 : 1);
+  // decode batches (32-row tiles) on a short K: 128-wide workgroups need half the K-slices to fill the chip, and
+  // with 32 chunks the slices are what the launch costs (o_proj 4096 x 4096 at 32 rows, with its merge-and-norm:
+  // 15.2 -> 12.3 us; down_proj, 112 chunks, 19.7 -> 21.1 and keeps the wide form)
+  if (mm_rt(M) == 2 && ns == 1 && K / 128 <= 32 && !grouped) spw = 2;
   while (spw > 1 && N % (4 * spw * sw)) spw >>= 1;
   if (const int o = env_int("MI355Q_MM_SPW", 0); o > 0 && o <= 4 / ns && (o & (o - 1)) == 0) spw = o;   // experiments
   const int bw = 4 * spw * sw;
