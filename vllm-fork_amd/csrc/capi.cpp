@@ -32,7 +32,8 @@ int check_launch(const char* what) {
 namespace {
 struct Knob { const char* name; bool read; const char* value; };
 std::mutex g_env_mu;
-Knob g_knobs[64];
+constexpr int MAX_KNOBS = 256;
+Knob g_knobs[MAX_KNOBS];
 int g_nknobs = 0;
 }  // namespace
 
@@ -41,17 +42,19 @@ const char* env_value(const char* name) {
   for (int i = 0; i < g_nknobs; i++)
     if (!strcmp(g_knobs[i].name, name)) return g_knobs[i].value;
   const char* v = getenv(name);
-  if (g_nknobs < 64) g_knobs[g_nknobs++] = Knob{name, true, v ? strdup(v) : nullptr};
+  if (g_nknobs < MAX_KNOBS) g_knobs[g_nknobs++] = Knob{name, true, v ? strdup(v) : nullptr};
   return v;
 }
-void env_override(const char* name, const char* value) {
+bool env_override(const char* name, const char* value) {
   std::lock_guard<std::mutex> lock(g_env_mu);
   for (int i = 0; i < g_nknobs; i++)
     if (!strcmp(g_knobs[i].name, name)) {
       g_knobs[i].value = value ? strdup(value) : nullptr;   // old strings are left alone: readers may hold them
-      return;
+      return true;
     }
-  if (g_nknobs < 64) g_knobs[g_nknobs++] = Knob{strdup(name), true, value ? strdup(value) : nullptr};
+  if (g_nknobs == MAX_KNOBS) return false;
+  g_knobs[g_nknobs++] = Knob{strdup(name), true, value ? strdup(value) : nullptr};
+  return true;
 }
 bool env_flag(const char* name) { return env_value(name) != nullptr; }
 int env_int(const char* name, int dflt) {
@@ -85,7 +88,8 @@ int reset_argmax_state(hipStream_t stream);      // elementwise.hip
 extern "C" int mi355q_set_option(const char* name, const char* value) {
   if (!name || strncmp(name, "MI355Q_", 7) != 0)
     return mi355q::set_error(MI355Q_EINVAL, "set_option: option names start with MI355Q_");
-  mi355q::env_override(name, value);
+  if (!mi355q::env_override(name, value))
+    return mi355q::set_error(MI355Q_ENOSPACE, "set_option: the option table is full (%s not set)", name);
   return MI355Q_OK;
 }
 

@@ -10,6 +10,14 @@
 // the stream pools of a torch process (32 per priority and device)
 #define MI355Q_STATE_BANKS 64
 
+// The in-kernel hand-offs (partition merge of the attention kernels, ticketed split-K merges) publish with
+// agent-scope relaxed atomic stores -- write-through (sc1) on gfx950 -- followed by s_waitcnt vmcnt(0), a barrier
+// and a relaxed ticket, and read with agent-scope atomic loads; no release fence.  That is a property of this
+// target's code generation and caches, not of the HIP memory model: refuse to build the device code for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libmi355q device code is written for gfx950 only (fence-free write-through hand-offs, MFMA shapes, LDS-DMA)"
+#endif
+
 namespace mi355q {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;

@@ -2320,7 +2320,7 @@ static StreamRowsPlan plan_stream_rows(int M, int N, int K, int G, int sw) {
   // for the tiled kernel with its K-slice merge, o_proj 12.4 + norm against 7.4 + merge-and-norm 6) -- the
   // tiled kernel shares one activation tile between 256 channels and keeps those layers.  On 32- and
   // 112-wide strips streaming wins (qkv 12.7 against 11.7 + 6.4, gate_up 23.5 against 23.2 + 5.6).
-  static const int min_ns = env_int("MI355Q_STREAM_ROWS_MIN_NS", 2);
+  const int min_ns = env_int("MI355Q_STREAM_ROWS_MIN_NS", 2);
   if (ns < min_ns || chunks % 8 || (long)(N / sw) < 64) return sp;
   const int per = chunks / 8;
   const int cands[5] = {8, 7, 4, 2, 1};
@@ -2365,7 +2365,7 @@ constexpr int MM_RT = 4;
 // 32 rows or fewer (decode batches beyond the GEMV kernels' reach): 32-row tiles, half the matrix-core
 // and accumulator work per weight chunk of the 64-row tile
 static inline int mm_rt(int M) {
-  static const int rt2_max = env_int("MI355Q_MM_RT2_MAX", 32);
+  const int rt2_max = env_int("MI355Q_MM_RT2_MAX", 32);
   return M <= rt2_max ? 2 : MM_RT;
 }
 
@@ -2570,7 +2570,7 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
     BurstPlan bp = plan_burst(moe ? 1 : M, K, G, ns, zc != nullptr);
     const char* nb = env_value("MI355Q_NO_BURST");
     const long blocks = moe ? (long)(N / sw) * M : (long)(N / sw) * ((M + 15) / 16);
-    static const int split_below = env_int("MI355Q_SPLIT_BELOW", 64);   // fewer strips than this: K-sliced kernel (80 strips of 8192 k: 5.9 us here, 7.6 K-sliced)
+    const int split_below = env_int("MI355Q_SPLIT_BELOW", 64);   // fewer strips than this: K-sliced kernel (80 strips of 8192 k: 5.9 us here, 7.6 K-sliced)
     const bool want_split = !epi_silu && (split_k > 1 || blocks < split_below);
     if (moe) {
       bp.ok = bp.ok && pro != PRO_ADDNORM && bias == nullptr && moe->expert_ids && moe->x_row_div >= 1;
