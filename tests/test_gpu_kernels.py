@@ -711,6 +711,52 @@ def test_paged_attention_vs_oracle(H, KVH, D, bs, fp8):
 
 
 @pytest.mark.parametrize("fp8", [False, True])
+def test_decode_step_attention_serving_batch_vs_oracle(fp8):
+    """32 sequences of about 1024 tokens, Llama-3-8B heads (the (32, 1024) shape of the benchmark: 1280 workgroups,
+    several dispatch rounds, every sequence's partitions merged in the kernel): the fused decode step against the
+    oracle's attention over the cache it leaves behind, at the tolerance of the reference's kernel test."""
+    rng = np.random.default_rng(32)
+    H, KVH, D, bs, S = 32, 8, 128, 16, 32
+    lens = [int(v) for v in rng.integers(990, 1060, size=S)]
+    x = 16 if fp8 else 8
+    per = (max(lens) + bs - 1) // bs
+    nblk = S * per
+    scale = 1.0 / D ** 0.5
+    ks, vs = (1 / 64, 1 / 32) if fp8 else (1.0, 1.0)
+    kst = torch.tensor(ks, dtype=torch.float32, device=DEV)
+    vst = torch.tensor(vs, dtype=torch.float32, device=DEV)
+    kf = rng.uniform(-1, 1, (nblk, KVH, D // x, bs, x)).astype(np.float32)
+    vf = rng.uniform(-1, 1, (nblk, KVH, D, bs)).astype(np.float32)
+    if fp8:
+        kcd = torch.from_numpy(orc.f32_to_e4m3(kf / ks)).to(DEV)
+        vcd = torch.from_numpy(orc.f32_to_e4m3(vf / vs)).to(DEV)
+    else:
+        kcd, vcd = to_dev(orc.f32_to_h16(kf)), to_dev(orc.f32_to_h16(vf))
+    bt = rng.permutation(nblk).reshape(S, per).astype(np.int32)
+    sl = np.array(lens, dtype=np.int32)
+    qkv = to_dev(orc.f32_to_h16(rng.uniform(-1, 1, (S, (H + 2 * KVH) * D)).astype(np.float32)))
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+    fr = torch.einsum("i,j->ij", torch.arange(2048, dtype=torch.float), inv)
+    cache = torch.cat((fr.cos(), fr.sin()), -1).to(torch.bfloat16).to(DEV)
+    pos = torch.from_numpy(sl.astype(np.int64) - 1).to(DEV)
+    P = (max(lens) + 255) // 256
+    out = torch.zeros((S, H, D), dtype=torch.bfloat16, device=DEV)
+    es = torch.empty((S, H, P), dtype=torch.float32, device=DEV)
+    ml = torch.empty_like(es)
+    tmp = torch.empty((S, H, P, D), dtype=torch.bfloat16, device=DEV)
+    ops.decode_attention_fused(out, es, ml, tmp, qkv, pos, cache, kcd, vcd, H, KVH, D, scale, torch.from_numpy(bt).to(DEV),
+                               torch.from_numpy(sl).to(DEV), bs, max(lens), "fp8" if fp8 else "auto", kst, vst)
+    # the oracle attends over the cache the step has left behind, with the rotated query
+    q = qkv[:, :H * D].clone()
+    k = qkv[:, H * D:(H + KVH) * D].clone()
+    ops.rotary_embedding(pos, q, k, D, cache, True)
+    kc_after = kcd.cpu().numpy() if fp8 else to_bits(kcd)
+    vc_after = vcd.cpu().numpy() if fp8 else to_bits(vcd)
+    ref = orc.paged_attention(to_bits(q.view(S, H, D)), kc_after, vc_after, bt, sl, scale, fp8=fp8, k_scale=ks, v_scale=vs)
+    np.testing.assert_allclose(f32(to_bits(out)), f32(ref), rtol=1e-5, atol=1e-3 if not fp8 else 1e-2)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
 def test_paged_attention_inline_merge_equals_merge_kernel(fp8, monkeypatch):
     """Partitions merged inside the attention kernel (last workgroup to arrive) give the output of
     the stand-alone merge kernel (to one rounding step), call after call on the same scratch buffers with
