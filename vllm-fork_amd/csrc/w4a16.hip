@@ -2165,7 +2165,9 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
 // row tile do not fit beside the weight ring and the activation fragments at two waves per SIMD); the
 // slices are summed across waves at the end.  Same arithmetic and rounding as the other kernels.
 // ---------------------------------------------------------------------------
-template <typename DT, int NS, int CPW, bool HAS_ZC>
+// REGACC: the running sums stay in registers (the per-chunk read-modify-write of the LDS slice is gone; same
+// operations in the same order, so the same bits) -- where ring, fragments and two sets of sums fit in 256 registers.
+template <typename DT, int NS, int CPW, bool HAS_ZC, bool REGACC = false>
 __global__ __launch_bounds__(512) void w4a16_stream_rows_kernel(const MmParams p, int bursts) {
   constexpr int SW = 16 * NS, QW = 4 * NS, RT = 2, NW = 8;
   extern __shared__ __attribute__((aligned(16))) float red[];   // [NW][32][SW]
@@ -2213,6 +2215,13 @@ __global__ __launch_bounds__(512) void w4a16_stream_rows_kernel(const MmParams p
   };
   float* mine = red + (size_t)wave * 32 * SW + ml * SW + QW * kq;   // + 16 rt SW + 4 sub
   const int last = cfirst + CPW * bursts - 1;
+  f32x4 tot[REGACC ? RT : 1][REGACC ? NS : 1];
+  if constexpr (REGACC) {
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int sub = 0; sub < NS; sub++) tot[rt][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   for (int burst = 0; burst < bursts; burst++) {
 #pragma unroll
     for (int i = 0; i < CPW; i++) {
@@ -2265,11 +2274,17 @@ __global__ __launch_bounds__(512) void w4a16_stream_rows_kernel(const MmParams p
         }
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
-          f32x4* dst = reinterpret_cast<f32x4*>(mine + 16 * rt * SW + 4 * sub);
-          f32x4 t = (burst == 0 && i == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : *dst;
+          if constexpr (REGACC) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) t[r] = __builtin_fmaf(sc[r], __builtin_fmaf(-zz[r], acc1[rt][r], acc[rt][sub][r]), t[r]);
-          *dst = t;
+            for (int r = 0; r < 4; r++)
+              tot[rt][sub][r] = __builtin_fmaf(sc[r], __builtin_fmaf(-zz[r], acc1[rt][r], acc[rt][sub][r]), tot[rt][sub][r]);
+          } else {
+            f32x4* dst = reinterpret_cast<f32x4*>(mine + 16 * rt * SW + 4 * sub);
+            f32x4 t = (burst == 0 && i == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : *dst;
+#pragma unroll
+            for (int r = 0; r < 4; r++) t[r] = __builtin_fmaf(sc[r], __builtin_fmaf(-zz[r], acc1[rt][r], acc[rt][sub][r]), t[r]);
+            *dst = t;
+          }
         }
       }
 #pragma unroll
@@ -2278,6 +2293,12 @@ __global__ __launch_bounds__(512) void w4a16_stream_rows_kernel(const MmParams p
         for (int rt = 0; rt < RT; rt++) xc[ks][rt] = xn[ks][rt];
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+  if constexpr (REGACC) {
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int sub = 0; sub < NS; sub++) *reinterpret_cast<f32x4*>(mine + 16 * rt * SW + 4 * sub) = tot[rt][sub];
   }
   __syncthreads();
   for (int it = threadIdx.x; it < Mt * QW; it += 512) {
@@ -2304,6 +2325,7 @@ struct StreamRowsPlan {
   bool ok;
   int ns, cpw, bursts;
   size_t lds;
+  bool regacc;
 };
 
 // rows 17..32, strips that alone occupy the chip, K that eight waves divide.  The kernel itself takes up to 64
@@ -2311,7 +2333,7 @@ struct StreamRowsPlan {
 // tiled kernel reads them once and wins: gate_up at 64 rows 42.0 -> 33.0 us, qkv 23.0 -> 19.5; whole decode step
 // at batch 48 4.27 -> 3.80 ms, batch 64 4.82 -> 4.29 ms.
 static StreamRowsPlan plan_stream_rows(int M, int N, int K, int G, int sw) {
-  StreamRowsPlan sp{false, 0, 0, 0, 0};
+  StreamRowsPlan sp{false, 0, 0, 0, 0, false};
   const int max_rows = env_int("MI355Q_STREAM_ROWS_MAX", 32);   // looked up per call: mi355q_set_option switches it
   if (M < 17 || M > max_rows || G % 128 || K % 128 || sw % 16 || N % sw) return sp;
   const int ns = sw / 16, chunks = K / 128;
@@ -2323,9 +2345,16 @@ static StreamRowsPlan plan_stream_rows(int M, int N, int K, int G, int sw) {
   const int min_ns = env_int("MI355Q_STREAM_ROWS_MIN_NS", 2);
   if (ns < min_ns || chunks % 8 || (long)(N / sw) < 64) return sp;
   const int per = chunks / 8;
+  // Running sums in registers: 32-wide strips, and 112-wide strips with a one-chunk ring (two chunks of ring and two
+  // sets of sums do not fit in 256 registers).  gate_up at 17 / 32 rows 19.6 -> 16.7 / 21.8 -> 20.3 us; qkv does not
+  // move (12.2 us: bound by the activation fragments every workgroup reads from L2, 5 x its weights).
+  // MI355Q_STREAM_ROWS_REGACC = 0 keeps the sums in LDS, 1 leaves 112-wide strips on the two-chunk ring.
+  const int regacc = env_int("MI355Q_STREAM_ROWS_REGACC", 2);
   const int cands[5] = {8, 7, 4, 2, 1};
   for (int cpw : cands) {
     if (per % cpw || cpw * ns > 16 || !stream_rows_built(ns, cpw)) continue;
+    if (regacc == 2 && ns == 7 && cpw != 1) continue;
+    sp.regacc = (regacc >= 1 && ns == 2) || (regacc == 2 && ns == 7 && cpw == 1);
     sp.ok = true; sp.ns = ns; sp.cpw = cpw; sp.bursts = per / cpw;
     sp.lds = (size_t)8 * 32 * sw * sizeof(float);
     return sp;
@@ -2342,6 +2371,14 @@ static int launch_stream_rows(const MmParams& p, const StreamRowsPlan& sp, hipSt
     else hipLaunchKernelGGL((w4a16_stream_rows_kernel<DT, NS_, CPW_, false>), grid, block, sp.lds, stream, p, sp.bursts);      \
     return check_launch("w4a16_stream_rows_kernel");                                                                     \
   }
+#define MI355Q_SRR(NS_, CPW_)                                                                                            \
+  if (sp.regacc && sp.ns == NS_ && sp.cpw == CPW_) {                                                                     \
+    if (p.zc) hipLaunchKernelGGL((w4a16_stream_rows_kernel<DT, NS_, CPW_, true, true>), grid, block, sp.lds, stream, p, sp.bursts);  \
+    else hipLaunchKernelGGL((w4a16_stream_rows_kernel<DT, NS_, CPW_, false, true>), grid, block, sp.lds, stream, p, sp.bursts);      \
+    return check_launch("w4a16_stream_rows_kernel");                                                                     \
+  }
+  MI355Q_SRR(2, 1) MI355Q_SRR(2, 2) MI355Q_SRR(2, 4) MI355Q_SRR(7, 1)
+#undef MI355Q_SRR
   MI355Q_SR(1, 1) MI355Q_SR(1, 2) MI355Q_SR(1, 4) MI355Q_SR(1, 7) MI355Q_SR(1, 8)
   MI355Q_SR(2, 1) MI355Q_SR(2, 2) MI355Q_SR(2, 4)
   MI355Q_SR(4, 1) MI355Q_SR(4, 2) MI355Q_SR(4, 4)
