@@ -280,6 +280,20 @@ int mi355q_topk_softmax(float* topk_weights, int32_t* topk_ids, const void* gati
                         int num_tokens, int num_experts, int topk, int renormalize, int dtype,
                         mi355q_stream_t stream);
 /*
+ * The router of a decoder layer at decode sizes as one launch, one workgroup per token: the
+ * post-attention fused_add_rms_norm (in place on input and residual, as mi355q_fused_add_rms_norm), the
+ * 16-bit gate projection logits[t, e] = round(input[t, :] . router_weight[e, :]) and mi355q_topk_softmax
+ * of the logits, each stage with the arithmetic of its stand-alone entry point (same bits).  Replaces the
+ * sequence post_attention_layernorm -> gate -> fused_topk of vllm/model_executor/models/mixtral.py:284,
+ * 144-146.  logits ([T, E] in `dtype`) may be NULL.  Up to 64 experts, hidden a multiple of 8 up to 8192
+ * (mi355q_moe_router_topk_supported); other layers run the three entry points one after the other.
+ */
+int mi355q_moe_router_topk_supported(int num_experts, int hidden);
+int mi355q_moe_router_topk(void* input, int64_t input_stride, void* residual, const void* norm_weight,
+                           float epsilon, const void* router_weight, void* logits, float* topk_weights,
+                           int32_t* topk_ids, int num_tokens, int num_experts, int hidden, int topk,
+                           int renormalize, int dtype, mi355q_stream_t stream);
+/*
  * Expert GEMM for decode: output row r ("slot" = one (token, selected expert) pair) is
  *   c[r, :] = x[r / x_row_div, :] * dequant(W[expert_ids[r]])      (fuse_silu_mul = 0)
  *   c[r, :] = (silu(x[r, :K]) * x[r, K:2K]) * dequant(W[expert_ids[r]])   (fuse_silu_mul = 1)

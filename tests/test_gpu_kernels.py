@@ -1276,6 +1276,39 @@ def test_topk_softmax(T, E, topk, renorm, dt):
     torch.testing.assert_close(w.cpu(), ref_w, rtol=2e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("T,E,H,topk,renorm,dt", [(1, 8, 4096, 2, True, torch.bfloat16), (3, 8, 4096, 2, True, torch.float16),
+                                                   (2, 64, 1024, 6, False, torch.bfloat16), (16, 7, 6144, 3, True, torch.bfloat16),
+                                                   (5, 60, 2048, 4, True, torch.bfloat16), (2, 3, 136, 1, False, torch.float16)])
+def test_moe_router_topk_equals_the_three_launches(T, E, H, topk, renorm, dt):
+    """One launch for add + RMSNorm, gate projection and softmax top-k: every output (residual, normalised row,
+    logits, weights, ids) holds the bits of fused_add_rms_norm -> linear_skinny -> topk_softmax."""
+    torch.manual_seed(T * E + H)
+    x = torch.randn((T, H), device=DEV).to(dt)
+    res = torch.randn((T, H), device=DEV).to(dt)
+    nw = (1 + 0.1 * torch.randn(H, device=DEV)).to(dt)
+    router = (torch.randn((E, H), device=DEV) / H ** 0.5).to(dt)
+    router[1] = router[0]                                # tied logits: the lower expert index wins
+    assert ops.moe_router_topk_supported(E, H)
+    x0, r0 = x.clone(), res.clone()
+    ops.fused_add_rms_norm(x0, r0, nw, 1e-5)
+    lg0 = ops.linear_skinny(x0, router)
+    w0 = torch.empty((T, topk), dtype=torch.float32, device=DEV)
+    i0 = torch.empty((T, topk), dtype=torch.int32, device=DEV)
+    ops.topk_softmax(w0, i0, None, lg0, renorm)
+    x1, r1 = x.clone(), res.clone()
+    w1, i1, lg1 = ops.moe_router_topk(x1, r1, nw, 1e-5, router, topk, renorm, return_logits=True)
+    assert torch.equal(r1, r0) and torch.equal(x1, x0)
+    assert torch.equal(lg1, lg0)
+    assert torch.equal(i1, i0) and torch.equal(w1, w0)
+    # and against the oracle's norm, for the stand-alone meaning of the outputs
+    odt = orc.BF16 if dt == torch.bfloat16 else orc.FP16
+    _, want_r = orc.fused_add_rms_norm(to_bits(x), to_bits(res), to_bits(nw), 1e-5, odt)
+    np.testing.assert_array_equal(to_bits(r1), want_r)
+    assert not ops.moe_router_topk_supported(65, 4096) and not ops.moe_router_topk_supported(8, 8200)
+    with pytest.raises(RuntimeError, match="up to 64 experts"):
+        ops.moe_router_topk(x1, r1, nw, 1e-5, torch.zeros((65, H), dtype=dt, device=DEV), 2, True)
+
+
 def _moe_case(g, tag):
     m, n, k, e, topk, G, has_zp = [int(v) for v in g[tag + "_meta"]]
     w1 = (g[tag + "_w1_q"], g[tag + "_w1_s"], g[tag + "_w1_z"] if has_zp else None)

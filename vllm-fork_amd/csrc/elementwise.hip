@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "row_ops.h"
 
 namespace mi355q {
 
@@ -108,59 +109,14 @@ __global__ __launch_bounds__(NT) void fused_add_rms_norm_kernel(
   }
 }
 
-// Rows that fit in registers (H <= 8 NT VPT elements, 16-byte aligned): x, residual and the norm
-// weight are all requested before anything is consumed, so the row costs one memory round trip,
-// one reduction and one write.  Same per-element arithmetic as the kernel above.
+// Rows that fit in registers (H <= 8 NT VPT elements, 16-byte aligned): see add_rms_norm_row_vec.
 template <typename DT, int NT, int VPT>
 __global__ __launch_bounds__(NT) void fused_add_rms_norm_vec_kernel(
     uint16_t* __restrict__ xio, int64_t x_stride, uint16_t* __restrict__ residual,
     const uint16_t* __restrict__ w, float eps, int H) {
   __shared__ float scratch[NT / 64];
-  u32x4* x = reinterpret_cast<u32x4*>(xio + (size_t)blockIdx.x * x_stride);
-  u32x4* r = reinterpret_cast<u32x4*>(residual + (size_t)blockIdx.x * H);
-  const u32x4* wv = reinterpret_cast<const u32x4*>(w);
-  const int nv = H >> 3;
-  u32x4 xv[VPT], rv[VPT], ww[VPT];
-#pragma unroll
-  for (int j = 0; j < VPT; j++) {
-    const int i = min((int)threadIdx.x + j * NT, nv - 1);   // clamped: the loads stay unconditional
-    xv[j] = x[i];
-    rv[j] = r[i];
-    ww[j] = w ? wv[i] : u32x4{0, 0, 0, 0};
-  }
-  float z[VPT][8];
-  float ss = 0.f;
-#pragma unroll
-  for (int j = 0; j < VPT; j++) {
-    const bool live = (int)threadIdx.x + j * NT < nv;
-    u32x4 zo;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const uint16_t z0 = DT::from_f32(DT::to_f32((uint16_t)(xv[j][e] & 0xffff)) + DT::to_f32((uint16_t)(rv[j][e] & 0xffff)));
-      const uint16_t z1 = DT::from_f32(DT::to_f32((uint16_t)(xv[j][e] >> 16)) + DT::to_f32((uint16_t)(rv[j][e] >> 16)));
-      zo[e] = (uint32_t)z0 | ((uint32_t)z1 << 16);
-      z[j][2 * e] = DT::to_f32(z0);
-      z[j][2 * e + 1] = DT::to_f32(z1);
-      if (live) ss += z[j][2 * e] * z[j][2 * e] + z[j][2 * e + 1] * z[j][2 * e + 1];
-    }
-    if (live) r[threadIdx.x + j * NT] = zo;
-  }
-  const float rs = rsqrtf(block_sum<NT / 64>(ss, scratch) / (float)H + eps);
-#pragma unroll
-  for (int j = 0; j < VPT; j++) {
-    if ((int)threadIdx.x + j * NT >= nv) continue;
-    u32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      float a = z[j][2 * e] * rs, b = z[j][2 * e + 1] * rs;
-      if (w) {
-        a *= DT::to_f32((uint16_t)(ww[j][e] & 0xffff));
-        b *= DT::to_f32((uint16_t)(ww[j][e] >> 16));
-      }
-      o[e] = (uint32_t)DT::from_f32(a) | ((uint32_t)DT::from_f32(b) << 16);
-    }
-    x[threadIdx.x + j * NT] = o;
-  }
+  add_rms_norm_row_vec<DT, NT, VPT>(xio + (size_t)blockIdx.x * x_stride, residual + (size_t)blockIdx.x * H, w, eps, H,
+                                    scratch, nullptr);
 }
 
 // The same from fp32 K-slice partials: c = round(sum_s partial[s]) (+ bias, rounded again) stands in

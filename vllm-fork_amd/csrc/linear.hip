@@ -7,20 +7,9 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "row_ops.h"
 
 namespace mi355q {
-
-template <typename DT>
-__device__ inline float dot2(uint32_t a, uint32_t b, float c);
-template <>
-__device__ inline float dot2<BF16>(uint32_t a, uint32_t b, float c) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
-}
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-template <>
-__device__ inline float dot2<FP16>(uint32_t a, uint32_t b, float c) {
-  return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
-}
 
 // MB = activation rows handled per pass (1, 2, 4, 8); R = weight rows per wave iteration.
 template <typename DT, int MB>

@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "row_ops.h"
 
 namespace mi355q {
 
@@ -14,23 +15,15 @@ __device__ inline float load_as_f32(const void* p, size_t i) {
   else return FP16::to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
 }
 
-// One wave per token.  probs = softmax(gating[t, :]) in fp32; the top-k are taken by k rounds
-// of arg-max (ties -> lowest expert index, as torch.topk on a descending stable order);
-// renormalize divides the selected probabilities by their sum.
-template <int DTID, int PER_LANE>
-__global__ __launch_bounds__(64) void topk_softmax_kernel(float* __restrict__ topk_weights,
-                                                          int32_t* __restrict__ topk_ids,
-                                                          const void* __restrict__ gating, int E,
-                                                          int topk, int renormalize) {
-  const int t = blockIdx.x, lane = threadIdx.x;
-  float v[PER_LANE];
+// One wave, one token.  v holds the wave's logits (lane + 64 i; -inf past E).  probs = softmax in fp32;
+// the top-k are taken by k rounds of arg-max (ties -> lowest expert index, as torch.topk on a descending
+// stable order); renormalize divides the selected probabilities by their sum.
+template <int PER_LANE>
+__device__ __forceinline__ void topk_softmax_wave(float (&v)[PER_LANE], int lane, int E, int topk, int renormalize,
+                                                  float* __restrict__ weights_row, int32_t* __restrict__ ids_row) {
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < PER_LANE; i++) {
-    const int e = lane + 64 * i;
-    v[i] = e < E ? load_as_f32<DTID>(gating, (size_t)t * E + e) : -INFINITY;
-    mx = fmaxf(mx, v[i]);
-  }
+  for (int i = 0; i < PER_LANE; i++) mx = fmaxf(mx, v[i]);
   mx = wave_max(mx);
   float sum = 0.f;
 #pragma unroll
@@ -65,8 +58,91 @@ __global__ __launch_bounds__(64) void topk_softmax_kernel(float* __restrict__ to
     if (lane == j) { my_w = w; my_id = best_e; }
   }
   if (lane < topk) {
-    topk_weights[(size_t)t * topk + lane] = renormalize ? my_w / picked_sum : my_w;
-    topk_ids[(size_t)t * topk + lane] = my_id;
+    weights_row[lane] = renormalize ? my_w / picked_sum : my_w;
+    ids_row[lane] = my_id;
+  }
+}
+
+template <int DTID, int PER_LANE>
+__global__ __launch_bounds__(64) void topk_softmax_kernel(float* __restrict__ topk_weights,
+                                                          int32_t* __restrict__ topk_ids,
+                                                          const void* __restrict__ gating, int E,
+                                                          int topk, int renormalize) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  float v[PER_LANE];
+#pragma unroll
+  for (int i = 0; i < PER_LANE; i++) {
+    const int e = lane + 64 * i;
+    v[i] = e < E ? load_as_f32<DTID>(gating, (size_t)t * E + e) : -INFINITY;
+  }
+  topk_softmax_wave<PER_LANE>(v, lane, E, topk, renormalize, topk_weights + (size_t)t * topk, topk_ids + (size_t)t * topk);
+}
+
+// The router of a decoder layer at decode sizes in one launch, one workgroup per token:
+//   residual = round(x + residual); x = RMSNorm(residual) * norm_w      (as fused_add_rms_norm)
+//   logits = round(x . router_w[e, :])                                   (as the 16-bit skinny linear)
+//   softmax + top-k of the logits                                        (as topk_softmax)
+// with every stage's arithmetic in the order of the stand-alone kernel, so the results are the same
+// bits.  The router rows of a wave's first two experts are requested before the norm starts: the
+// launch then costs one memory round trip, two reductions and the selection.  E <= 64,
+// H <= 2048 VPT.
+template <typename DT, int VPT>
+__global__ __launch_bounds__(256) void moe_router_topk_kernel(uint16_t* __restrict__ x, int64_t x_stride,
+                                                              uint16_t* __restrict__ residual,
+                                                              const uint16_t* __restrict__ norm_w, float eps,
+                                                              const uint16_t* __restrict__ router_w,
+                                                              uint16_t* __restrict__ logits_out,
+                                                              float* __restrict__ topk_weights,
+                                                              int32_t* __restrict__ topk_ids, int E, int H,
+                                                              int topk, int renormalize) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* xs = reinterpret_cast<u32x4*>(smem);                         // [H / 8] the normalised row
+  uint16_t* lg = reinterpret_cast<uint16_t*>(smem + (size_t)H * 2);   // [64] logits
+  float* scratch = reinterpret_cast<float*>(lg + 64);                 // [4]
+  const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kv = H >> 3;
+  constexpr int PV = 4 * VPT;   // vectors of a router row per lane
+  u32x4 wa[PV], wb[PV];
+  auto request = [&](int n) {
+    const u32x4* w0 = reinterpret_cast<const u32x4*>(router_w + (size_t)min(n, E - 1) * H);
+    const u32x4* w1 = reinterpret_cast<const u32x4*>(router_w + (size_t)min(n + 1, E - 1) * H);
+#pragma unroll
+    for (int i = 0; i < PV; i++) {
+      const int v = min(lane + 64 * i, kv - 1);
+      wa[i] = w0[v];
+      wb[i] = w1[v];
+    }
+  };
+  request(2 * wave);
+  add_rms_norm_row_vec<DT, 256, VPT>(x + (size_t)t * x_stride, residual + (size_t)t * H, norm_w, eps, H, scratch, xs);
+  __syncthreads();
+  for (int n = 2 * wave; n < E; n += 8) {
+    if (n != 2 * wave) request(n);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PV; i++) {
+      const int v = lane + 64 * i;
+      if (v < kv) {
+        const u32x4 xv = xs[v];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          a0 = dot2<DT>(wa[i][e], xv[e], a0);
+          a1 = dot2<DT>(wb[i][e], xv[e], a1);
+        }
+      }
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == 0) {
+      lg[n] = DT::from_f32(a0);
+      if (n + 1 < E) lg[n + 1] = DT::from_f32(a1);
+    }
+  }
+  __syncthreads();
+  if (logits_out && threadIdx.x < E) logits_out[(size_t)t * E + threadIdx.x] = lg[threadIdx.x];
+  if (wave == 0) {
+    float v[1] = {lane < E ? DT::to_f32(lg[lane]) : -INFINITY};
+    topk_softmax_wave<1>(v, lane, E, topk, renormalize, topk_weights + (size_t)t * topk, topk_ids + (size_t)t * topk);
   }
 }
 
@@ -187,6 +263,40 @@ extern "C" int mi355q_topk_softmax(float* topk_weights, int32_t* topk_ids, const
 #undef MI355Q_TKD
 #undef MI355Q_TK
   return check_launch("topk_softmax_kernel");
+}
+
+extern "C" int mi355q_moe_router_topk_supported(int num_experts, int hidden) {
+  return num_experts >= 1 && num_experts <= 64 && hidden >= 8 && hidden % 8 == 0 && hidden <= 8192;
+}
+
+extern "C" int mi355q_moe_router_topk(void* input, int64_t input_stride, void* residual, const void* norm_weight,
+                                      float epsilon, const void* router_weight, void* logits, float* topk_weights,
+                                      int32_t* topk_ids, int num_tokens, int num_experts, int hidden, int topk,
+                                      int renormalize, int dtype, mi355q_stream_t stream) {
+  if (num_tokens == 0) return MI355Q_OK;
+  MI355Q_REQUIRE(input && residual && router_weight && topk_weights && topk_ids, "moe_router_topk: null pointer");
+  MI355Q_REQUIRE(dtype == MI355Q_BF16 || dtype == MI355Q_FP16, "moe_router_topk: dtype must be bf16 or fp16");
+  MI355Q_REQUIRE(mi355q_moe_router_topk_supported(num_experts, hidden),
+                 "moe_router_topk: %d experts over %d channels (up to 64 experts, hidden a multiple of 8 up to 8192)",
+                 num_experts, hidden);
+  MI355Q_REQUIRE(topk >= 1 && topk <= num_experts, "moe_router_topk: topk=%d out of range", topk);
+  MI355Q_REQUIRE(input_stride >= hidden && input_stride % 8 == 0, "moe_router_topk: bad input stride");
+  MI355Q_REQUIRE((((uintptr_t)input | (uintptr_t)residual | (uintptr_t)norm_weight | (uintptr_t)router_weight) & 15) == 0,
+                 "moe_router_topk: pointers must be 16-byte aligned");
+  const size_t lds = (size_t)hidden * 2 + 64 * 2 + 4 * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define MI355Q_RT(DT, VPT)                                                                                          \
+  hipLaunchKernelGGL((moe_router_topk_kernel<DT, VPT>), dim3(num_tokens), dim3(256), lds, s, (uint16_t*)input,     \
+                     input_stride, (uint16_t*)residual, (const uint16_t*)norm_weight, epsilon,                     \
+                     (const uint16_t*)router_weight, (uint16_t*)logits, topk_weights, topk_ids, num_experts, hidden, \
+                     topk, renormalize)
+  if (dtype == MI355Q_BF16) {
+    if (hidden <= 4096) MI355Q_RT(BF16, 2); else MI355Q_RT(BF16, 4);
+  } else {
+    if (hidden <= 4096) MI355Q_RT(FP16, 2); else MI355Q_RT(FP16, 4);
+  }
+#undef MI355Q_RT
+  return check_launch("moe_router_topk_kernel");
 }
 
 extern "C" int mi355q_moe_sum(void* out, const void* expert_out, const float* topk_weights,

@@ -56,6 +56,9 @@ _SIGS = {
     "mi355q_w4a16_mm_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "mi355q_w4a16_mm_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "mi355q_topk_softmax": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_moe_router_topk_supported": (c_int, [c_int, c_int]),
+    "mi355q_moe_router_topk": (c_int, [c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_vp]),
     "mi355q_moe_w4a16_gemm": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_moe_align_block_size": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),

@@ -39,6 +39,8 @@ class LlamaConfig:
 # workgroup of that GEMM repeats the norm, which beats the separate launch for one row (1.71 vs
 # 1.79 ms per step) and loses from two rows on (batch 4: 2.15 vs 2.03 ms)
 FUSE_NORM_MAX_TOKENS = int(os.environ.get("MI355Q_FUSE_NORM_MAX", "1"))
+# up to this many tokens the MoE router runs norm, gate projection and top-k as one launch (one workgroup per token)
+ROUTER_FUSED_MAX_TOKENS = int(os.environ.get("MI355Q_ROUTER_FUSED_MAX", "16"))
 
 CONFIGS = {
     "llama3-8b": LlamaConfig("llama3-8b", 4096, 14336, 32, 32, 8, 128, 128256),
@@ -228,9 +230,17 @@ class MoeBlock:
             cpu = lambda w: tuple(None if t is None else t.cpu() for t in w)
             self.checkpoint = (cpu(w13), cpu(w2))
 
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, residual: torch.Tensor | None = None, norm_weight: torch.Tensor | None = None,
+                 eps: float = 0.0) -> torch.Tensor:
+        """With `residual`: x is the attention block's output, and the post-attention add + norm runs here (in
+        place on both, inside the router's launch at decode sizes)."""
         from .plugin.moe import fused_experts, fused_topk
         T = x.shape[0]
+        if residual is not None and T <= ROUTER_FUSED_MAX_TOKENS and ops.moe_router_topk_supported(*self.router.shape):
+            w, ids = ops.moe_router_topk(x, residual, norm_weight, eps, self.router, self.top_k, True)
+            return fused_experts(x, self.w13, self.w2, w, ids)
+        if residual is not None:
+            ops.fused_add_rms_norm(x, residual, norm_weight, eps)
         logits = ops.linear_skinny(x, self.router) if T <= 16 else torch.nn.functional.linear(x, self.router)
         w, ids = fused_topk(logits, self.top_k, True)      # Mixtral renormalises the selected weights
         return fused_experts(x, self.w13, self.w2, w, ids)
@@ -422,9 +432,9 @@ class LlamaRunner:
         else:
             o = self._all_reduce(L["o"](attn.view(T, qs)))
         if "moe" in L:   # router, top-k, experts, weighted sum (mixtral.py:126-130); all-reduce of the partial sums
-            if not o_normed:
-                ops.fused_add_rms_norm(o, residual, L["ln2"], cfg.rms_eps)
-            return self._all_reduce(L["moe"](o)), residual, False
+            if o_normed:
+                return self._all_reduce(L["moe"](o)), residual, False
+            return self._all_reduce(L["moe"](o, residual, L["ln2"], cfg.rms_eps)), residual, False
         tail = next_norm is not None and self._tail_norm_ok(T, L["down"]) if self.quant != "none" else False
 
         def down(act, **kw):

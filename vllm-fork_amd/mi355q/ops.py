@@ -484,6 +484,32 @@ def topk_softmax(topk_weights: torch.Tensor, topk_ids: torch.Tensor, token_exper
                                          topk_weights.shape[1], int(renormalize), _dt(gating_output, True), _stream()))
 
 
+def moe_router_topk_supported(num_experts: int, hidden: int) -> bool:
+    return bool(_lib.lib().mi355q_moe_router_topk_supported(num_experts, hidden))
+
+
+def moe_router_topk(x: torch.Tensor, residual: torch.Tensor, norm_weight: torch.Tensor | None, epsilon: float,
+                    router_weight: torch.Tensor, topk: int, renormalize: bool, return_logits: bool = False):
+    """fused_add_rms_norm(x, residual, norm_weight) in place, logits = x @ router_weight.T, then topk_softmax of
+    the logits, as one launch (mixtral.py:284,144-146 -> fused_topk).  Returns (fp32 weights [T, topk], int32 ids
+    [T, topk]) and, on request, the logits [T, E]; every result holds the bits the three ops give one after the
+    other."""
+    _need_cuda(x, residual, router_weight)
+    if x.dim() != 2 or x.stride(1) != 1 or residual.shape != x.shape or not residual.is_contiguous():
+        raise RuntimeError("moe_router_topk: x must be [tokens, hidden] with unit inner stride, residual contiguous of the same shape")
+    E, H = router_weight.shape
+    if H != x.shape[1] or not router_weight.is_contiguous() or router_weight.dtype != x.dtype or residual.dtype != x.dtype:
+        raise RuntimeError("moe_router_topk: router_weight must be a contiguous [experts, hidden] tensor of the activation dtype")
+    T = x.shape[0]
+    w = torch.empty((T, topk), dtype=torch.float32, device=x.device)
+    ids = torch.empty((T, topk), dtype=torch.int32, device=x.device)
+    logits = torch.empty((T, E), dtype=x.dtype, device=x.device) if return_logits else None
+    check(_lib.lib().mi355q_moe_router_topk(x.data_ptr(), x.stride(0), residual.data_ptr(), _ptr(norm_weight), epsilon,
+                                            router_weight.data_ptr(), _ptr(logits), w.data_ptr(), ids.data_ptr(), T, E, H,
+                                            topk, int(renormalize), _dt(x), _stream()))
+    return (w, ids, logits) if return_logits else (w, ids)
+
+
 def moe_w4a16_gemm(x: torch.Tensor, w: PackedMoeW4, expert_ids: torch.Tensor, x_row_div: int,
                    fuse_silu_mul: bool = False, silu_pairs: bool = False) -> torch.Tensor:
     """Row r of the result = x[r // x_row_div] (or silu-mul of x[r]) @ dequant(expert expert_ids[r]).
