@@ -169,6 +169,30 @@ def test_fp8_checkpoints_resolve_to_the_weight_only_scheme(strategy, act, static
     assert cfg.has_blocked_weights() == (strategy == "block")
 
 
+@pytest.mark.parametrize("block,dynamic,w8a8", [([128, 128], True, True), ([64, 64], True, False), ([128, 128], False, False)])
+def test_block_quantised_fp8_w8a8_checkpoints(block, dynamic, w8a8, monkeypatch):
+    """schemes/compressed_tensors_w8a8_fp8.py:69-79: 128 x 128 weight blocks with dynamic activation scales take the
+    activation-quantising scheme (one scale per token and 128-wide group); other block shapes, and static
+    activation scales (which the reference rejects, :72), are served weight-only."""
+    from mi355q.plugin.compressed_tensors import CompressedTensorsW8A8Fp8
+    monkeypatch.delenv("MI355Q_FP8_LINEAR", raising=False)
+    act = {"num_bits": 8, "type": "float", "symmetric": True, "strategy": "group" if dynamic else "tensor",
+           "dynamic": dynamic}
+    if dynamic:
+        act["group_size"] = block[0]
+    cfg = make(fp8_config("block", act, block))
+    lin = MergedColumnParallelLinear(512, [256, 256], bias=False, params_dtype=torch.bfloat16, quant_config=cfg,
+                                     prefix="model.layers.0.mlp.gate_up_proj", return_bias=False)
+    assert type(lin.scheme) is (CompressedTensorsW8A8Fp8 if w8a8 else CompressedTensorsW8A16Fp8)
+    assert lin.weight_scale.shape == (512 // block[0], 512 // block[1])
+    lin.process_weights_after_loading()
+    assert lin.weight_scale.dtype == torch.float32 and lin.mi355q_scale_block == tuple(block)
+    assert getattr(lin, "input_scale", None) is None
+    with pytest.raises(ValueError, match="128 x 128"):
+        CompressedTensorsW8A8Fp8(QuantizationArgs.model_validate(
+            {"num_bits": 8, "type": "float", "strategy": "block", "block_structure": [64, 128]}), False)
+
+
 @pytest.mark.parametrize("strategy,dynamic", [("tensor", False), ("tensor", True), ("channel", False), ("channel", True)])
 def test_fp8_w8a8_checkpoints_resolve_to_the_activation_quantising_scheme(strategy, dynamic, monkeypatch):
     """compressed_tensors.py:831-846: an fp8 W8A8 checkpoint with tensor / channel weight scales takes the

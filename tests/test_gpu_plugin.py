@@ -797,6 +797,45 @@ def test_compressed_tensors_fp8_weight_only(strategy, monkeypatch):
     assert (to_bits(got) == ref).mean() > 0.97
 
 
+@pytest.mark.parametrize("T", [2, 90])
+def test_compressed_tensors_fp8_w8a8_block(T, monkeypatch):
+    """float-quantized fp8 checkpoint with 128 x 128 weight blocks and dynamic activation groups
+    (schemes/compressed_tensors_w8a8_fp8.py:69-79,167-174): one run-time scale per token and 128-wide group,
+    then the block-scaled product.  Against the oracle's restatement of both steps on the same bytes."""
+    from mi355q.plugin import CompressedTensorsConfig
+    from mi355q.plugin.compressed_tensors import CompressedTensorsW8A8Fp8
+    monkeypatch.delenv("MI355Q_FP8_LINEAR", raising=False)
+    rng = np.random.default_rng(43)
+    hidden, inter = 512, 768
+    w_args = {"num_bits": 8, "type": "float", "symmetric": True, "strategy": "block", "dynamic": False,
+              "block_structure": [128, 128]}
+    act = {"num_bits": 8, "type": "float", "symmetric": True, "strategy": "group", "group_size": 128, "dynamic": True}
+    cfg = CompressedTensorsConfig.from_config({
+        "quant_method": "compressed-tensors", "format": "float-quantized", "ignore": ["lm_head"],
+        "config_groups": {"group_0": {"targets": ["Linear"], "weights": w_args, "input_activations": act}}})
+    cfg.packed_modules_mapping = _CT_FUSED
+    with torch.device(DEV):
+        gu = MergedColumnParallelLinear(hidden, [inter, inter], bias=False, params_dtype=torch.bfloat16,
+                                        quant_config=cfg, prefix="model.layers.0.mlp.gate_up_proj", return_bias=False)
+    assert type(gu.scheme) is CompressedTensorsW8A8Fp8 and gu.scheme.strategy == "block"
+    ws, ss = [], []
+    for i in range(2):
+        w8 = orc.f32_to_e4m3((rng.standard_normal((inter, hidden)) * 30).astype(np.float32))
+        s = (0.001 + 0.002 * rng.random((inter // 128, hidden // 128))).astype(np.float32)
+        gu.weight_loader(gu.weight, torch.from_numpy(w8).view(torch.float8_e4m3fn), i)
+        gu.weight_loader(gu.weight_scale, torch.from_numpy(s), i)
+        ws.append(w8)
+        ss.append(s)
+    gu.process_weights_after_loading()
+    assert gu.weight_scale.shape == (2 * inter // 128, hidden // 128)
+    x = orc.f32_to_h16(rng.standard_normal((T, hidden)).astype(np.float32))
+    xq, xs = orc.per_token_group_quant_fp8(x, 128)
+    ref = orc.w8a8_block_scaled_mm(xq, np.concatenate(ws), xs, np.concatenate(ss), [128, 128])
+    got = gu(to_dev(x))
+    np.testing.assert_allclose(f32(to_bits(got)), f32(ref), rtol=1e-2, atol=1e-2 * float(np.abs(f32(ref)).max()))
+    assert (to_bits(got) == ref).mean() > 0.9
+
+
 @pytest.mark.parametrize("T", [3, 200])
 @pytest.mark.parametrize("strategy,dynamic", [("tensor", False), ("tensor", True), ("channel", False),
                                               ("channel", True)])

@@ -94,6 +94,16 @@ __global__ __launch_bounds__(512) void linear_mfma_kernel(const uint16_t* __rest
   const int m0 = blockIdx.y * rows_pp;
   const int mb = min(rows_pp, M - m0);
   const int kv = K >> 3, astride = K + 8;
+  const int n_begin = blockIdx.x * rows_per_block;
+  const int n_end = min(N, n_begin + rows_per_block);
+  // the wave's first weights are requested before the activations are staged: they depend on nothing
+  u32x4 wf[8], wnx[8];
+  const int n_first = n_begin + wave * 16;
+  if (K >= 256) {
+    const uint16_t* wrow = w + (size_t)min(n_first + ml, N - 1) * K + 8 * kq;
+#pragma unroll
+    for (int j = 0; j < 8; j++) wf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + 32 * j));
+  }
   // four requests in flight per thread: one at a time would pay an L2 round trip per iteration
   for (int base = threadIdx.x; base < mb * kv; base += 4 * 512) {
     u32x4 t[4];
@@ -115,17 +125,14 @@ __global__ __launch_bounds__(512) void linear_mfma_kernel(const uint16_t* __rest
     }
   }
   __syncthreads();
-  const int n_begin = blockIdx.x * rows_per_block;
-  const int n_end = min(N, n_begin + rows_per_block);
   const uint16_t* arow = xs + (size_t)min(ml, mb - 1) * astride + 8 * kq;
-  for (int n0 = n_begin + wave * 16; n0 < n_end; n0 += 8 * 16) {
+  for (int n0 = n_first; n0 < n_end; n0 += 8 * 16) {
     const uint16_t* wrow = w + (size_t)min(n0 + ml, N - 1) * K + 8 * kq;
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
     int k0 = 0;
     // the next 256 k of weights are requested before the current ones are multiplied (two register
     // sets); the scheduling barrier keeps the requests ahead of the arithmetic
-    u32x4 wf[8], wnx[8];
-    if (K >= 256) {
+    if (K >= 256 && n0 != n_first) {
 #pragma unroll
       for (int j = 0; j < 8; j++) wf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + 32 * j));
     }

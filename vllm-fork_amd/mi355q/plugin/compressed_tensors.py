@@ -24,9 +24,9 @@ the input dimension (`weight_packed` int32 [N, K*bits/32]), zero points along th
 
 Other schemes that quantize activations (W8A8 int8, W4A8, nvfp4 / mxfp4 / mxfp8) are a different arithmetic
 path and are not built: asking for their scheme raises NotImplementedError naming the scheme.  A
-block-quantised fp8 W8A8 checkpoint (and any fp8 W8A8 checkpoint under MI355Q_FP8_LINEAR=w8a16) is served
-weight-only (its activation scale is loaded and dropped), which is what the reference does on devices
-without fp8 matrix support (compressed_tensors.py:831-837).
+block-quantised fp8 W8A8 checkpoint with blocks other than 128 x 128 (and any fp8 W8A8 checkpoint under
+MI355Q_FP8_LINEAR=w8a16) is served weight-only (its activation scale is loaded and dropped), which is what
+the reference does on devices without fp8 matrix support (compressed_tensors.py:831-837).
 """
 import math
 import os
@@ -366,22 +366,39 @@ class CompressedTensorsW8A16Fp8(CompressedTensorsScheme):
 
 
 class CompressedTensorsW8A8Fp8(CompressedTensorsW8A16Fp8):
-    """schemes/compressed_tensors_w8a8_fp8.py:60-207 for the tensor and channel weight strategies: activations
-    are quantised to fp8 -- with the checkpoint's input_scale (static: the largest over fused shards, :193-194)
-    or with one run-time scale per token (dynamic: kFp8DynamicTokenSym, :47-50) -- and the product runs as a
-    scaled fp8 x fp8 matrix product.  Per-tensor weights of a fused layer are requantised to their largest scale
+    """schemes/compressed_tensors_w8a8_fp8.py:60-207: activations are quantised to fp8 -- with the checkpoint's
+    input_scale (static: the largest over fused shards, :193-194), with one run-time scale per token (dynamic:
+    kFp8DynamicTokenSym, :47-50), or, for 128 x 128 block-quantised weights, with one run-time scale per token
+    and 128-wide group (:69-79) -- and the product runs as a scaled fp8 x fp8 matrix product.  Per-tensor weights of a fused layer are requantised to their largest scale
     (process_fp8_weight_tensor_strategy, fp8_utils.py:1321-1346); per-channel weights keep their scales
     (process_fp8_weight_channel_strategy, :1349-1364).  Checkpoint tensors are those of the weight-only
     scheme."""
 
+    @staticmethod
+    def block_shape_served(block_structure) -> bool:
+        """Weight blocks the block-scaled product takes: 128 x 128 (the activation groups are as wide as a block
+        is tall, :73, and one group must span exactly one block of K)."""
+        return block_structure is not None and list(block_structure) == [128, 128]
+
     def __init__(self, weight_quant: QuantizationArgs, is_static_input_scheme: bool):
         super().__init__(weight_quant, is_static_input_scheme)
         if self.strategy == "block":
-            raise ValueError("block-quantised fp8 weights run weight-only (CompressedTensorsW8A16Fp8)")
+            if self.is_static_input_scheme:      # :72
+                raise ValueError("block-quantised fp8 weights take dynamic activation scales only")
+            if not self.block_shape_served(self.weight_block_size):
+                raise ValueError(f"block-quantised fp8 W8A8 serves 128 x 128 blocks, not {self.weight_block_size}; "
+                                 "other shapes run weight-only (CompressedTensorsW8A16Fp8)")
 
     def process_weights_after_loading(self, layer) -> None:
         from .fp8 import FP8_MAX
         w, ws = layer.weight.data, layer.weight_scale.data.to(torch.float32)
+        if self.strategy == "block":              # :167-174: weights and [N/bn, K/bk] scales stay as loaded
+            _set(layer, "weight", w)
+            _set(layer, "weight_scale", ws.contiguous())
+            if hasattr(layer, "input_scale"):
+                _set(layer, "input_scale", None)
+            layer.mi355q_scale_block = tuple(self.weight_block_size)
+            return
         if self.strategy == "tensor":
             ws = ws.reshape(-1)
             max_s = ws.max()
@@ -409,6 +426,13 @@ class CompressedTensorsW8A8Fp8(CompressedTensorsW8A16Fp8):
 
     def apply_weights(self, layer, x, bias=None):
         x2 = x.reshape(-1, x.shape[-1])
+        if self.strategy == "block":
+            # one run-time scale per token and 128-wide group, then the block-scaled product
+            # (W8A8BlockFp8LinearOp, fp8_utils.py:533-659)
+            bn, bk = self.weight_block_size
+            xq, xs = ops.per_token_group_quant_fp8(x2.contiguous(), bk)
+            out = ops.w8a8_block_scaled_mm(xq, layer.weight.data, xs, layer.weight_scale.data, [bn, bk], x.dtype, bias)
+            return out.reshape(x.shape[:-1] + (out.shape[-1],))
         if self.is_static_input_scheme:
             xq, xs = ops.scaled_fp8_quant(x2, scale=layer.input_scale.data)
         else:
@@ -565,9 +589,12 @@ class CompressedTensorsConfig(QuantizationConfig):
                                           actorder=weight_quant.actorder, layer_name=layer_name)
         if is_activation_quantization_format(format):
             if self._is_fp8_w8a8(weight_quant, input_quant):
-                # block-quantised weights (their activations would need per-token-group scales) and
-                # MI355Q_FP8_LINEAR=w8a16 are served weight-only: the activation arguments are then ignored
-                if weight_quant.strategy != "block" and os.environ.get("MI355Q_FP8_LINEAR", "w8a8") == "w8a8":
+                # block shapes other than 128 x 128 and MI355Q_FP8_LINEAR=w8a16 are served weight-only: the
+                # activation arguments are then ignored
+                blocked = weight_quant.strategy == "block"
+                served = not blocked or (input_quant.dynamic and
+                                         CompressedTensorsW8A8Fp8.block_shape_served(weight_quant.block_structure))
+                if served and os.environ.get("MI355Q_FP8_LINEAR", "w8a8") == "w8a8":
                     return CompressedTensorsW8A8Fp8(weight_quant=weight_quant,
                                                     is_static_input_scheme=not input_quant.dynamic)
                 return CompressedTensorsW8A16Fp8(weight_quant=weight_quant,
