@@ -273,19 +273,20 @@ def cpu_baseline_opt125m(budget_s=6.0):
                       "oracle/opt125m.py, batch 1, prompt 32" % steps, "sample_seconds": el}
 
 
-def time_allreduce_16k(dev, reps=200):
+def time_allreduce_16k(dev, reps=200, fn=None):
     """The TP exchange of a 70B decode step: sum all-reduce of one [1, 8192] bf16 row (16 KiB) on the default
     process group.  Eager: `reps` back-to-back calls between two events; captured: the same calls inside one
     HIP graph, replayed.  Microseconds per all-reduce, (eager, captured or None, capture error or None)."""
+    fn = fn or torch.distributed.all_reduce      # or the peer-memory exchange (same calls on every rank)
     x = torch.ones(8192, dtype=torch.bfloat16, device=dev)
     for _ in range(10):
-        torch.distributed.all_reduce(x)
+        fn(x)
         x.fill_(1.0)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
-        torch.distributed.all_reduce(x)
+        fn(x)
     b.record()
     torch.cuda.synchronize()
     eager = a.elapsed_time(b) * 1e3 / reps
@@ -298,7 +299,7 @@ def time_allreduce_16k(dev, reps=200):
         with torch.cuda.stream(s):
             with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):   # the group's watchdog thread keeps querying events
                 for _ in range(50):
-                    torch.distributed.all_reduce(x)
+                    fn(x)
             g.replay()
             s.synchronize()
             x.fill_(1.0)
@@ -375,7 +376,8 @@ def main():
         runner.reset(in_len)
 
     # ---- decode ------------------------------------------------------------------------------
-    graph = not args.no_graph and not (dist_on and torch.distributed.get_backend() == "gloo")
+    # collectives staged through the host (gloo) cannot be captured; with the exchange over peer memory the step has none
+    graph = not args.no_graph and not (dist_on and torch.distributed.get_backend() == "gloo" and runner.peer_ar is None)
     graph_error = None
     if graph:
         try:
@@ -452,6 +454,14 @@ def main():
         ar_eager, ar_graph, ar_err = time_allreduce_16k(dev)
         out["allreduce_us_16k"] = {"eager": ar_eager, "captured": ar_graph, "capture_error": ar_err, "world": world,
                                    "backend": "nccl (RCCL)"}
+    if world > 1 or runner.peer_ar is not None:
+        # which exchange the decode step used: one kernel over peer memory, or the group's collectives
+        out["tp_exchange"] = "peer memory, one-shot" if runner.peer_ar is not None else \
+            "process group (%s): %s" % (torch.distributed.get_backend(), getattr(runner, "peer_ar_note", ""))
+        if runner.peer_ar is not None:
+            pe, pg, perr = time_allreduce_16k(dev, fn=runner.peer_ar.all_reduce)
+            out["peer_allreduce_us_16k"] = {"eager": pe, "captured": pg, "capture_error": perr, "world": world,
+                                            "timeouts": runner.peer_ar.timeouts()}
     if rank == 0:
         out["roofline"] = time_dominant_kernel(runner, B)
     if rank == 0 and n_gpus == 1 and not args.skip_cpu:

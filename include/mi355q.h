@@ -728,6 +728,43 @@ int mi355q_apply_repetition_penalties(void* logits, const uint8_t* prompt_mask,
                                       const uint8_t* output_mask, const void* penalties,
                                       int num_seqs, int vocab, int dtype, mi355q_stream_t stream);
 
+/* ------------------------------------------------------------------ */
+/* One-shot all-reduce over peer memory (tensor-parallel decode)       */
+/* ------------------------------------------------------------------ */
+/*
+ * Sum of a small 16-bit tensor over the ranks of a tensor-parallel group, one process per GPU, through
+ * regions of uncached device memory that every rank maps from every peer (xGMI): a call pushes the
+ * input into all regions as 8-byte {data, epoch} granules, sweeps its own region until every rank's
+ * granules carry the epoch, and adds them in rank order in fp32 (all ranks compute the same bits).  One
+ * kernel, no host synchronisation, capturable; the epoch is device state advanced by the kernel.
+ * Replaces the reference's custom / quick all-reduce for the [tokens, hidden] sums behind o_proj and
+ * down_proj (csrc/libtorch_stable/custom_all_reduce.cu:165-200, csrc/custom_all_reduce.cuh:291-305,
+ * csrc/quickreduce/quick_reduce.h:117-215; Python side vllm/distributed/device_communicators/
+ * quick_all_reduce.py:44-62, cuda_communicator.py:275-340).  Life cycle as the reference's:
+ *   init (allocates the region; 2..8 ranks; max_bytes a multiple of 16 up to 8 MiB: the largest tensor)
+ *   -> get_handle (mi355q_peer_ar_handle_bytes() bytes) -> exchange the handles by any means
+ *   -> open_handles (all ranks' handles in rank order; this rank's own entry is ignored)
+ *   -> all_reduce ... -> destroy.
+ * all_reduce: num_elements even, at most max_bytes; input may equal output.  Calls on one communicator must
+ * be stream-ordered, and every rank must make the same sequence of calls.  A rank that waits longer than
+ * MI355Q_PEER_AR_TIMEOUT_MS (default 1000) for a peer counts a timeout and returns garbage instead of
+ * hanging: mi355q_peer_ar_timeouts synchronises the device and reports the count.
+ */
+int mi355q_peer_ar_handle_bytes(void);
+int mi355q_peer_ar_init(int rank, int world_size, size_t max_bytes, void** comm_out);
+int mi355q_peer_ar_get_handle(void* comm, void* handle_out);
+int mi355q_peer_ar_open_handles(void* comm, const void* handles);
+size_t mi355q_peer_ar_max_bytes(void* comm);
+int mi355q_peer_ar_all_reduce(void* comm, const void* input, void* output, size_t num_elements, int dtype,
+                              mi355q_stream_t stream);
+/* The same exchange without the sum: output [rows, world * row_elements] holds, in every row, the ranks' rows side by
+ * side in rank order (the vocabulary-parallel logits before sampling; replaces the all-gather of
+ * cuda_communicator.py:342-390 at decode sizes).  rows * row_elements * 2 <= max_bytes; not in place. */
+int mi355q_peer_ar_all_gather(void* comm, const void* input, void* output, int rows, size_t row_elements, int dtype,
+                              mi355q_stream_t stream);
+int mi355q_peer_ar_timeouts(void* comm, int* timeouts_out);
+int mi355q_peer_ar_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

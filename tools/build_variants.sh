@@ -11,7 +11,7 @@ while [ $# -gt 1 ]; do
   name=$1; flags=$2; shift 2
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $flags -c w4a16.hip -o /tmp/variants_obj/w4a16_$name.o &&
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libmi355q_$name.so /tmp/variants_obj/w4a16_$name.o \
-      w8a16.o w8a8.o moe.o elementwise.o linear.o attention.o sampler.o capi.o && echo "built $name" ) &
+      w8a16.o w8a8.o moe.o elementwise.o linear.o attention.o sampler.o allreduce.o capi.o && echo "built $name" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

@@ -27,7 +27,8 @@ for n in [int(a) for a in sys.argv[2:]]:
         same += 1
     line = json.loads(open(f"{out}/bench_tp{n}.json").read().strip().splitlines()[-1])
     print(f"TP={n}: {same}/{len(ref)} leading decode steps equal to TP=1; first tokens {got[0]} vs {ref[0]}; "
-          f"tok/s {line['value']:.1f} graph={line['graph']} scaling={line['scaling']} n_gpus={line['n_gpus']}")
+          f"tok/s {line['value']:.1f} graph={line['graph']} scaling={line['scaling']} n_gpus={line['n_gpus']} "
+          f"exchange: {line.get('tp_exchange')} {line.get('peer_allreduce_us_16k')}")
     # partial sums are rounded per rank before the all-reduce, so a near-tie may flip late in the sequence;
     # the first eight steps must agree
     ok &= same >= 8

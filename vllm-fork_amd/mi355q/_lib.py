@@ -56,6 +56,15 @@ _SIGS = {
     "mi355q_w4a16_mm_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "mi355q_w4a16_mm_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "mi355q_topk_softmax": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "mi355q_peer_ar_handle_bytes": (c_int, []),
+    "mi355q_peer_ar_init": (c_int, [c_int, c_int, c_sz, ctypes.POINTER(c_vp)]),
+    "mi355q_peer_ar_get_handle": (c_int, [c_vp, c_vp]),
+    "mi355q_peer_ar_open_handles": (c_int, [c_vp, c_vp]),
+    "mi355q_peer_ar_max_bytes": (c_sz, [c_vp]),
+    "mi355q_peer_ar_all_reduce": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "mi355q_peer_ar_all_gather": (c_int, [c_vp, c_vp, c_vp, c_int, c_sz, c_int, c_vp]),
+    "mi355q_peer_ar_timeouts": (c_int, [c_vp, ctypes.POINTER(c_int)]),
+    "mi355q_peer_ar_destroy": (c_int, [c_vp]),
     "mi355q_moe_router_topk_supported": (c_int, [c_int, c_int]),
     "mi355q_moe_router_topk": (c_int, [c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int,
                                        c_int, c_int, c_int, c_vp]),

@@ -259,6 +259,14 @@ class LlamaRunner:
         # graph) execute on a one-GPU box exactly as a TP rank issues them
         self.tp_collectives = tp_size > 1 or (os.environ.get("MI355Q_FORCE_TP_PATH") == "1"
                                               and torch.distributed.is_available() and torch.distributed.is_initialized())
+        # decode-sized sums and the logits gather go over peer memory where the ranks can map each other's regions
+        # (its construction checks itself against the group's collectives and is all-or-nothing over the ranks)
+        self.peer_ar = None
+        if self.tp_collectives and (tp_size > 1 or os.environ.get("MI355Q_PEER_AR_LOOPBACK") == "1"):
+            from .plugin.peer_all_reduce import PeerAllReduce
+            ar = PeerAllReduce(group=tp_group, device=self.device)
+            self.peer_ar = None if ar.disabled else ar
+            self.peer_ar_note = ar.reason
         self.G = group_size
         self.kv_cache_dtype = kv_cache_dtype
         self.fp8 = kv_cache_dtype.startswith("fp8")
@@ -365,6 +373,8 @@ class LlamaRunner:
 
     def _all_reduce(self, x):
         if self.tp_collectives:
+            if self.peer_ar is not None and self.peer_ar.should_use(x):
+                return self.peer_ar.all_reduce(x)      # one kernel over peer memory (decode-sized sums)
             if self._host_staged():
                 t = x.cpu()
                 torch.distributed.all_reduce(t, group=self.tp_group)
@@ -484,6 +494,8 @@ class LlamaRunner:
         M = h.shape[0]
         # beyond 16 rows the BLAS GEMM is faster (lm_head of Llama-3-8B at 32 rows: 202 us against 231)
         logits = ops.linear_skinny(h, self.lm_head) if M <= 16 else torch.nn.functional.linear(h, self.lm_head)
+        if self.tp_collectives and self.peer_ar is not None and self.peer_ar.should_gather(logits):
+            return self.peer_ar.all_gather(logits)
         if self.tp_collectives:
             src = logits.cpu() if self._host_staged() else logits
             parts = [torch.empty_like(src) for _ in range(self.tp_size)]

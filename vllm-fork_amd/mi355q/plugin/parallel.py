@@ -6,12 +6,16 @@ communication_op.py)."""
 import torch
 import torch.distributed as dist
 
-_STATE = {"rank": 0, "size": 1, "group": None}
+_STATE = {"rank": 0, "size": 1, "group": None, "peer": None}
 
 
-def init_tensor_parallel(rank: int | None = None, size: int | None = None, group=None) -> None:
+def init_tensor_parallel(rank: int | None = None, size: int | None = None, group=None,
+                         peer_all_reduce: bool | None = None) -> None:
     """Adopt the default process group (or `group`) as the TP group.  With no process
-    group initialised the state stays at rank 0 of 1."""
+    group initialised the state stays at rank 0 of 1.  peer_all_reduce: build the one-shot exchange over
+    peer memory for decode-sized tensors (peer_all_reduce.PeerAllReduce; every rank must pass the same
+    value; default: when the ranks have GPUs), which the two collectives below then prefer -- what
+    CudaCommunicator does with its custom / quick all-reduce (cuda_communicator.py:275-340)."""
     if rank is None or size is None:
         if dist.is_available() and dist.is_initialized():
             rank, size = dist.get_rank(group), dist.get_world_size(group)
@@ -19,7 +23,20 @@ def init_tensor_parallel(rank: int | None = None, size: int | None = None, group
             rank, size = 0, 1
     if not 0 <= rank < size:
         raise ValueError(f"bad tensor-parallel rank {rank} of {size}")
-    _STATE.update(rank=rank, size=size, group=group)
+    if _STATE["peer"] is not None:
+        _STATE["peer"].close()
+    _STATE.update(rank=rank, size=size, group=group, peer=None)
+    if peer_all_reduce is None:
+        peer_all_reduce = size > 1 and torch.cuda.is_available()
+    if peer_all_reduce and size > 1:
+        from .peer_all_reduce import PeerAllReduce
+        ar = PeerAllReduce(group=group)
+        _STATE["peer"] = None if ar.disabled else ar
+
+
+def get_peer_all_reduce():
+    """The group's exchange over peer memory, or None where it could not be set up."""
+    return _STATE["peer"]
 
 
 def get_tensor_model_parallel_rank() -> int:
@@ -34,6 +51,9 @@ def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
     """Sum over the TP group.  In place on x (the reference returns a new tensor from its
     custom all-reduce; callers here never reuse the input)."""
     if _STATE["size"] > 1:
+        peer = _STATE["peer"]
+        if peer is not None and peer.should_use(x):
+            return peer.all_reduce(x)
         dist.all_reduce(x, group=_STATE["group"])
     return x
 
@@ -43,6 +63,9 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Te
     n = _STATE["size"]
     if n == 1:
         return x
+    peer = _STATE["peer"]
+    if peer is not None and x.dim() == 2 and dim in (-1, 1) and peer.should_gather(x):
+        return peer.all_gather(x)
     parts = [torch.empty_like(x) for _ in range(n)]
     dist.all_gather(parts, x.contiguous(), group=_STATE["group"])
     return torch.cat(parts, dim=dim)
