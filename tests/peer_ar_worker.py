@@ -39,6 +39,18 @@ def main():
         want = xi.float().cpu()
         dist.all_reduce(want)
         res["exact"] = bool(torch.equal(ar.all_reduce(xi.clone()).float().cpu(), want))
+        # ranks out of step: no host synchronisation between calls, every rank stalls its stream at different calls,
+        # sizes change from call to call; inputs are functions of (call, rank), so every rank knows the exact sum
+        base = torch.arange(16384, device=dev)
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        for it in range(400):
+            n = (2, 8192, 16384, 770)[it % 4]
+            if (it * 7 + rank * 3) % 5 == 0:
+                torch.cuda._sleep(150000 + 50000 * rank)
+            x = (((base[:n] + it * 7 + rank * 13) % 17) - 8).to(torch.bfloat16)
+            want = sum((((base[:n] + it * 7 + r * 13) % 17) - 8) for r in range(world)).to(torch.bfloat16)
+            bad += (ar.all_reduce(x) != want).sum()
+        res["skewed_series_mismatches"] = int(bad.item())
         # a replayed graph of 32 dependent reductions (what a decode step issues), timed
         x = torch.ones(8192, device=dev, dtype=torch.bfloat16) * (1.0 / 64)
         y = torch.empty_like(x)

@@ -26,7 +26,7 @@ def test_peer_all_reduce_ranks_share_the_gpu(world, port, tmp_path):
         res = json.load(open(tmp_path / f"rank{rank}.json"))
         assert not res["disabled"], res
         assert res["timeouts"] == 0 and res["exact"] and res["graph_value_ok"], res
-        assert res["worst_rel_err"] < 1e-2, res
+        assert res["worst_rel_err"] < 1e-2 and res["skewed_series_mismatches"] == 0, res
         assert res["plugin_peer"] and res["plugin_sum_ok"] and res["plugin_gather_ok"], res
         assert res["plugin_large_goes_to_group"] and res["plugin_timeouts"] == 0, res
         print(f"world {world} rank {rank}: {res['us_per_all_reduce_16k']:.2f} us per 16 KiB all-reduce (ranks share one GPU)")
