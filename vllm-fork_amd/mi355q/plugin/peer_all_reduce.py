@@ -47,6 +47,8 @@ class PeerAllReduce:
         ok, why = self._agree(ok, why)
         if ok and self_check:
             ok, why = self._agree(*self._self_check())
+        if ok and not self._host_group() and self.world > 1:
+            ok, why = self._not_slower_than_the_group()
         self.disabled, self.reason = (not ok), why
         if self.disabled:
             self.close()
@@ -171,6 +173,32 @@ class PeerAllReduce:
             return (not fail), fail
         except RuntimeError as e:
             return False, f"self-check failed: {e}"
+
+    def _not_slower_than_the_group(self):
+        """The exchange is kept only where it is at least as fast as the group's own all-reduce at the size it is
+        for (16 KiB, back-to-back calls; the slowest rank's times decide, so all ranks decide alike)."""
+        x = torch.ones(8192, dtype=torch.bfloat16, device=self.device)
+
+        def per_call(fn, reps=100):
+            for _ in range(10):
+                fn(x)
+            torch.cuda.synchronize(self.device)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn(x)
+            b.record()
+            torch.cuda.synchronize(self.device)
+            return a.elapsed_time(b) * 1e3 / reps
+
+        t = torch.tensor([per_call(self.all_reduce), per_call(lambda v: dist.all_reduce(v, group=self.group))],
+                         dtype=torch.float32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        mine, theirs = float(t[0]), float(t[1])
+        self.us_16k = {"peer": mine, "group": theirs}
+        if self.timeouts() or mine > theirs:
+            return False, f"the group's all-reduce is faster at 16 KiB ({theirs:.1f} us against {mine:.1f})"
+        return True, ""
 
     # -- use ---------------------------------------------------------------------------------------
     def should_use(self, x: torch.Tensor) -> bool:
