@@ -92,6 +92,11 @@ int mi355q_w4a16_choose_tile(int K, int N, int G);
  * narrow to occupy the chip without splitting K across workgroups.
  */
 int mi355q_w4a16_choose_strip(int K, int N, int G);
+/* The same for the experts of a routed layer, where a decode launch runs decode_slots (tokens x top-k) rows with a
+ * workgroup per strip each: Mixtral's w2 (14336 -> 4096) at top-2 takes 32-wide strips, one round of 256 workgroups
+ * instead of two on 16-wide ones.  No counterpart in the reference (its expert GEMM has one tile shape per dtype,
+ * csrc/moe/moe_wna16.cu:16-350). */
+int mi355q_moe_w4a16_choose_strip(int K, int N, int G, int decode_slots);
 
 /* 2- and 3-bit GPTQ tensors -> the 4-bit checkpoint layout mi355q_w4a16_repack takes (device, load time).
  *   axis 0: src int32 [values * bits / 32, other], one bit string per column along K (qweight)

@@ -2834,7 +2834,10 @@ extern "C" int mi355q_moe_w4a16_gemm(const void* x, int ldx, int x_row_div, cons
 // workgroup per CU in as few rounds as possible (estimate: rounds x (fixed cost + strip bytes at
 // the per-CU ingest rate)).  Only widths the burst kernel is built for are considered; layers
 // with too few strips to occupy the chip keep the widths of the split-K capable kernel.
-extern "C" int mi355q_w4a16_choose_strip(int K, int N, int G) {
+// rows: the rows a decode launch runs at once with a workgroup each -- 1 for a dense layer, the (token, expert) slots
+// of a routed layer at batch 1 (top-k): two slots on 16-wide strips of a 4096-wide layer are two rounds of 256
+// workgroups, on 32-wide strips one
+static int choose_strip_for(int K, int N, int G, int rows) {
   if (G <= 0) G = K;
   const int legacy = mi355q_w4a16_choose_tile(K, N, G);
   if (env_flag("MI355Q_TILE") || (G % 128 && G != 64 && G != 32) || K % 128) return legacy;
@@ -2844,13 +2847,19 @@ extern "C" int mi355q_w4a16_choose_strip(int K, int N, int G) {
   for (int ns : cands) {
     const int sw = 16 * ns;
     if (N % sw || !tile_ok(sw, K, G) || !plan_burst(1, K, G, ns, false).ok) continue;
-    const int blocks = N / sw;
+    const int blocks = N / sw * rows;
     if (blocks < 128) continue;
     const int rounds = (blocks + 255) / 256;
     const double cost = rounds * (3.0 + (double)K * sw / 2 / 24e3);  // us; 24 GB/s per CU ~ 10 B/cycle
     if (cost < best_cost) { best_cost = cost; best = sw; }
   }
   return best ? best : legacy;
+}
+
+extern "C" int mi355q_w4a16_choose_strip(int K, int N, int G) { return choose_strip_for(K, N, G, 1); }
+
+extern "C" int mi355q_moe_w4a16_choose_strip(int K, int N, int G, int decode_slots) {
+  return choose_strip_for(K, N, G, decode_slots < 1 ? 1 : decode_slots);
 }
 
 extern "C" int mi355q_w4a16_gate_up_silu(const void* x, int ldx, const void* residual_in,

@@ -31,6 +31,7 @@ _SIGS = {
     "mi355q_reset_library_state": (c_int, [c_vp]),
     "mi355q_w4a16_choose_tile": (c_int, [c_int, c_int, c_int]),
     "mi355q_w4a16_choose_strip": (c_int, [c_int, c_int, c_int]),
+    "mi355q_moe_w4a16_choose_strip": (c_int, [c_int, c_int, c_int, c_int]),
     "mi355q_w4a16_repack": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_w4a16_repack_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mi355q_w4a16_unpack_host": (c_int, [c_vp, c_vp, c_int, c_int, c_int]),

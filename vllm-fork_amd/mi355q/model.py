@@ -223,8 +223,8 @@ class MoeBlock:
             w13 = (rows(w13[0], Il), rows(w13[1], Il), None if w13[2] is None else rows(w13[2], Il // 2))
             cols = lambda t, per: t[:, :, tp_rank * per:(tp_rank + 1) * per].contiguous()
             w2 = (cols(w2[0], Il // 2), cols(w2[1], Il // G), None if w2[2] is None else cols(w2[2], Il // G))
-        self.w13 = ops.moe_w4a16_repack(w13[0], w13[1], w13[2], G, pair_halves=True)
-        self.w2 = ops.moe_w4a16_repack(w2[0], w2[1], w2[2], G)
+        self.w13 = ops.moe_w4a16_repack(w13[0], w13[1], w13[2], G, pair_halves=True, decode_slots=cfg.top_k)
+        self.w2 = ops.moe_w4a16_repack(w2[0], w2[1], w2[2], G, decode_slots=cfg.top_k)
         self.checkpoint = None
         if keep_checkpoint:
             cpu = lambda w: tuple(None if t is None else t.cpu() for t in w)

@@ -433,13 +433,13 @@ class PackedMoeW4:
 
 
 def moe_w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor | None,
-                     group_size: int, pair_halves: bool = False) -> PackedMoeW4:
+                     group_size: int, pair_halves: bool = False, tile: int = 0, decode_slots: int = 1) -> PackedMoeW4:
     """MoE WNA16 checkpoint-side layout (moe_wna16.py:204-330 after its loader conversions,
     :516-638) -> kernel layout.  qweight uint8 [E, N, K/2], two 4-bit values per byte along K with
     the even k in the low nibble; scales [E, N, K/G]; qzeros uint8 [E, N/2, K/G] (even n low) or
     None for symmetric uint4b8.  pair_halves (the merged w13 projection): gate_i next to up_i, for
     the SiluAndMul epilogue -- granted only where the layer shape supports it (see the result's
-    `pair_halves`)."""
+    `pair_halves`).  decode_slots: the layer's top-k, for the choice of the strip width."""
     if qweight.dtype != torch.uint8 or qweight.dim() != 3:
         raise RuntimeError("moe qweight must be uint8 [E, N, K/2]")
     E, N, K2 = qweight.shape
@@ -449,7 +449,8 @@ def moe_w4a16_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.
         raise RuntimeError(f"moe scales shape {tuple(scales.shape)} != ({E}, {N}, {K // G})")
     if qzeros is not None and (qzeros.dtype != torch.uint8 or qzeros.shape != (E, N // 2, K // G)):
         raise RuntimeError(f"moe qzeros must be uint8 [{E}, {N // 2}, {K // G}]")
-    tile = _lib.lib().mi355q_w4a16_choose_strip(K, N, G)
+    if tile == 0:    # decode_slots: the (token, expert) slots of a decode launch at batch 1, i.e. the layer's top-k
+        tile = _lib.lib().mi355q_moe_w4a16_choose_strip(K, N, G, decode_slots)
     pair_halves = bool(pair_halves) and w4a16_gate_up_silu_supported(K, N, G)
     packed = torch.empty((E, K * N // 8), dtype=torch.int32, device=qweight.device)
     sc = torch.empty((E, N // tile, K // G, tile), dtype=scales.dtype, device=qweight.device)

@@ -757,7 +757,8 @@ class CompressedTensorsWNA16MoEMethod:
             qw = w.data.transpose(1, 2).contiguous().view(torch.uint8)
             # zero points: the words seen as bytes hold two output channels each, [E, K/G, N/2] -> [E, N/2, K/G]
             qz = None if z is None else z.data.contiguous().view(torch.uint8).transpose(1, 2).contiguous()
-            return ops.moe_w4a16_repack(qw, s.data.transpose(1, 2).contiguous(), qz, layer.group_size, pair_halves=pair)
+            return ops.moe_w4a16_repack(qw, s.data.transpose(1, 2).contiguous(), qz, layer.group_size, pair_halves=pair,
+                                        decode_slots=int(getattr(layer, "top_k", 1)))
 
         z13 = None if self.symmetric else layer.w13_weight_zero_point
         z2 = None if self.symmetric else layer.w2_weight_zero_point

@@ -200,9 +200,11 @@ class MoeWNA16Method(QuantizeMethodBase):
     def process_weights_after_loading(self, layer) -> None:
         z13 = layer.w13_qzeros.data if self.quant_config.has_zp else None
         z2 = layer.w2_qzeros.data if self.quant_config.has_zp else None
+        slots = int(getattr(layer, "top_k", 1))
         layer.w13_packed = ops.moe_w4a16_repack(layer.w13_qweight.data, layer.w13_scales.data, z13, layer.group_size,
-                                                pair_halves=True)
-        layer.w2_packed = ops.moe_w4a16_repack(layer.w2_qweight.data, layer.w2_scales.data, z2, layer.group_size)
+                                                pair_halves=True, decode_slots=slots)
+        layer.w2_packed = ops.moe_w4a16_repack(layer.w2_qweight.data, layer.w2_scales.data, z2, layer.group_size,
+                                               decode_slots=slots)
         for name in ("w13_qweight", "w2_qweight", "w13_scales", "w2_scales", "w13_qzeros", "w2_qzeros"):
             if name in layer._parameters:
                 del layer._parameters[name]
