@@ -752,7 +752,7 @@ int mi355q_apply_repetition_penalties(void* logits, const uint8_t* prompt_mask,
  *   -> all_reduce ... -> destroy.
  * all_reduce: num_elements even, at most max_bytes; input may equal output.  Calls on one communicator must
  * be stream-ordered, and every rank must make the same sequence of calls.  A rank that waits longer than
- * MI355Q_PEER_AR_TIMEOUT_MS (default 1000) for a peer counts a timeout and returns garbage instead of
+ * MI355Q_PEER_AR_TIMEOUT_MS (default 5000) for a peer counts a timeout and returns garbage instead of
  * hanging: mi355q_peer_ar_timeouts synchronises the device and reports the count.
  */
 int mi355q_peer_ar_handle_bytes(void);

@@ -116,7 +116,7 @@ struct PeerArComm {
   bool opened[PEER_AR_MAX_WORLD] = {};
   uint32_t* state = nullptr;
   bool ready = false;
-  long long timeout_ticks = 100000000LL;      // one second
+  long long timeout_ticks = 500000000LL;      // five seconds: ranks may reach their first exchange far apart
 };
 
 }  // namespace mi355q
