@@ -27,6 +27,7 @@ def test_row_and_column_parallel_over_gloo(world, tmp_path):
     for r in range(world):
         res = json.load(open(tmp_path / f"rank{r}.json"))
         assert res["size"] == world
+        assert res["peer_exchange_absent"] or __import__("torch").cuda.is_available(), res
         # all-reduce of bf16 partials, bias added on rank 0 only; two addends have one possible sum
         assert res["tp_partials_close"] and (res["tp_exact"] or world > 2), res
         assert res["tp_close"] and res["bias_once"], res

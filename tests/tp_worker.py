@@ -42,7 +42,10 @@ def oracle_apply(self, layer, x, bias=None):
 
 def main():
     dist.init_process_group("gloo")
-    parallel.init_tensor_parallel()
+    # asking for the exchange over peer memory where no rank has a GPU: construction fails on every rank, all ranks
+    # agree on that, and the group's own collectives serve
+    parallel.init_tensor_parallel(peer_all_reduce=True)
+    peer_missing = parallel.get_peer_all_reduce() is None
     rank, size = parallel.get_tensor_model_parallel_rank(), parallel.get_tensor_model_parallel_world_size()
     MI355XW4A16LinearKernel.apply_weights = oracle_apply
 
@@ -103,7 +106,7 @@ def main():
     ref_logits = torch.nn.functional.linear(bf(x), w16)
 
     res = {
-        "rank": rank, "size": size,
+        "rank": rank, "size": size, "peer_exchange_absent": peer_missing,
         "tp_exact": bool(torch.equal(y, total)),
         # with more than two ranks the collective's summation order is its own: one bf16 ulp of slack
         "tp_partials_close": bool(torch.allclose(y.float(), total.float(), rtol=2 ** -7, atol=2 ** -7)),

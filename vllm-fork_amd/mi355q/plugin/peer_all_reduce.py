@@ -32,7 +32,9 @@ class PeerAllReduce:
         self._comm = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if device is None:
+            device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda:0"
+        self.device = torch.device(device)
         self.max_bytes = max_bytes
         if os.environ.get("MI355Q_PEER_AR", "1") == "0":
             self.reason = "switched off by MI355Q_PEER_AR=0"
@@ -77,10 +79,10 @@ class PeerAllReduce:
             check(L.mi355q_peer_ar_get_handle(self._comm, buf))
             mine = torch.tensor(list(bytes(buf)), dtype=torch.uint8)
             ok, why = True, ""
-        except RuntimeError as e:
+        except Exception as e:  # noqa: BLE001  (no device, no IPC, ...: whatever it is, the group keeps its collectives)
             hb = L.mi355q_peer_ar_handle_bytes()
             mine = torch.zeros(hb, dtype=torch.uint8)
-            ok, why = False, f"set-up failed: {e}"
+            ok, why = False, f"set-up failed: {type(e).__name__}: {e}"
         # the exchange runs on every rank, failed or not, so that no rank waits for another for ever
         where = "cpu" if self._host_group() else self.device
         parts = [torch.empty(hb, dtype=torch.uint8, device=where) for _ in range(self.world)]
@@ -90,8 +92,8 @@ class PeerAllReduce:
         try:
             handles = b"".join(bytes(p.cpu().tolist()) for p in parts)
             check(L.mi355q_peer_ar_open_handles(self._comm, handles))
-        except RuntimeError as e:
-            return False, f"opening the peers' regions failed: {e}"
+        except Exception as e:  # noqa: BLE001
+            return False, f"opening the peers' regions failed: {type(e).__name__}: {e}"
         return True, ""
 
     def _self_check(self):
