@@ -1,6 +1,6 @@
-"""Randomly drawn shapes through the prompt GEMM (whatever form the planner picks for each) and through both
-prompt attention kernels, against the oracle: the cases of tools/fuzz_mm.py and tools/fuzz_prefill_attention.py
-with fixed seeds (the tools take other seeds and counts on the command line)."""
+"""Randomly drawn shapes through the decode and prompt GEMMs (whatever kernel and form the planner picks for each) and
+through both prompt attention kernels, against the oracle: the cases of tools/fuzz_decode.py, tools/fuzz_mm.py and
+tools/fuzz_prefill_attention.py with fixed seeds (the tools take other seeds and counts on the command line)."""
 import importlib.util
 import os
 
@@ -15,6 +15,13 @@ def _tool(name):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_decode_gemm_random_shapes(seed):
+    """1 to 16 rows, GPTQ / AWQ, group sizes 32 to K, every strip width, bias, and the fused add + RMSNorm / SiLU
+    forms where the layer takes them; a strip width the library chose itself must never be refused."""
+    assert _tool("fuzz_decode").run(60, seed, verbose=False) == 0
 
 
 @pytest.mark.parametrize("seed", [11, 12])
