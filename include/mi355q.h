@@ -222,6 +222,20 @@ int mi355q_w4a16_mm_supported(int N, int K, int G, int tile);
 int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const void* scales, const void* zc,
                     const void* bias, void* c, int M, int N, int K, int G, int tile, int act_dtype,
                     int silu_pairs, void* workspace, size_t workspace_bytes, mi355q_stream_t stream);
+/*
+ * mi355q_w4a16_gemm_add_rms_norm whose input row is the combine of a routed layer: x = round(w0 y0 + w1 y1) in
+ * fp32 in slot order, expert_out [1, 2, K], topk_weights fp32 [1, 2] -- the bits of mi355q_moe_sum -- so that the
+ * decode step of a top-2 mixture-of-experts model needs no launch between the experts' down projection and the
+ * next layer's qkv projection (mixtral.py:126-130 final_hidden_states -> :280-284 input_layernorm of the next
+ * layer).  One token, two selected experts, a layer mi355q_..._supported accepts; other cases run mi355q_moe_sum
+ * and mi355q_w4a16_gemm_add_rms_norm.
+ */
+int mi355q_w4a16_gemm_moe_sum_add_rms_norm_supported(int num_tokens, int topk, int N, int K, int G, int tile);
+int mi355q_w4a16_gemm_moe_sum_add_rms_norm(const void* expert_out, const float* topk_weights, int topk,
+                                           const void* residual_in, void* residual_out, const void* norm_weight,
+                                           float epsilon, const void* packed, const void* scales, const void* zc,
+                                           const void* bias, void* c, int num_tokens, int N, int K, int G, int tile,
+                                           int act_dtype, mi355q_stream_t stream);
 /* mi355q_w4a16_mm followed by mi355q_fused_add_rms_norm on its result (row-parallel projection ->
  * residual add -> RMSNorm, vllm/model_executor/models/llama.py:311-328): residual = round(c + residual),
  * out = RMSNorm(residual) * norm_weight.  When the GEMM is cut into K-slices, the slice sums, the

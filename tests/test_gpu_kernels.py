@@ -1724,3 +1724,39 @@ def test_gptq_2_and_3_bit_checkpoints(bits, sym, v2, M, K, N, G):
     got, want = f32(to_bits(out)), f32(ref)
     assert np.allclose(got, want, rtol=1e-2, atol=1e-2)
     assert (to_bits(out) == ref).mean() > 0.97
+
+
+@pytest.mark.parametrize("K,N,awq,dt", [(4096, 6144, True, torch.bfloat16), (4096, 6144, False, torch.bfloat16),
+                                        (4096, 28672, False, torch.float16), (2048, 4096, True, torch.bfloat16)])
+def test_w4a16_gemm_moe_sum_add_rms_norm_equals_the_three_launches(K, N, awq, dt):
+    """The combine of a top-2 routed layer, the residual add, the norm and the projection as one launch: output and new
+    residual hold the bits of moe_sum -> w4a16_gemm_add_rms_norm."""
+    odt = orc.BF16 if dt == torch.bfloat16 else orc.FP16
+    rng = np.random.default_rng(K + N)
+    G = 128
+    q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    s = orc.f32_to_h16((0.05 * rng.random((K // G, N))).astype(np.float32), odt)
+    if awq:
+        z = rng.integers(0, 16, size=(K // G, N), dtype=np.int32)
+        w = ops.w4a16_repack(i32(orc.pack_cols(q, awq_order=True)), to_dev(s, odt), i32(orc.pack_cols(z, awq_order=True)), G,
+                             _lib.W_AWQ, _lib.ZP_AWQ)
+    else:
+        w = ops.w4a16_repack(i32(orc.gptq_pack(q)), to_dev(s, odt), None, G)
+    assert ops.w4a16_gemm_moe_sum_add_rms_norm_supported(1, 2, w)
+    assert not ops.w4a16_gemm_moe_sum_add_rms_norm_supported(2, 2, w) and not ops.w4a16_gemm_moe_sum_add_rms_norm_supported(1, 3, w)
+    torch.manual_seed(K)
+    y = torch.randn((1, 2, K), device=DEV).to(dt)
+    y[0, 0, :8] = 0.0                                     # signed zeros through the sum
+    y[0, 1, :4] = -0.0
+    tw = torch.tensor([[0.64, 0.36]], dtype=torch.float32, device=DEV)
+    res = torch.randn((1, K), device=DEV).to(dt)
+    nw = (1 + 0.1 * torch.randn(K, device=DEV)).to(dt)
+    x = torch.empty((1, K), dtype=dt, device=DEV)
+    ops.moe_sum(y, x, tw)
+    want, want_res = ops.w4a16_gemm_add_rms_norm(x, res, nw, 1e-5, w)
+    got, got_res = ops.w4a16_gemm_moe_sum_add_rms_norm(y, tw, res, nw, 1e-5, w)
+    assert torch.equal(got_res.view(torch.int16), want_res.view(torch.int16))
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    with pytest.raises(RuntimeError, match="one token, two selected experts"):
+        ops.w4a16_gemm_moe_sum_add_rms_norm(torch.zeros((1, 3, K), dtype=dt, device=DEV),
+                                            torch.zeros((1, 3), dtype=torch.float32, device=DEV), res, nw, 1e-5, w)

@@ -160,13 +160,18 @@ __global__ __launch_bounds__(256) void moe_sum_kernel(uint16_t* __restrict__ out
     const u32x4 x = *reinterpret_cast<const u32x4*>(y + ((size_t)t * topk + j) * H + 8 * v);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      acc[2 * e] += wj * DT::to_f32((uint16_t)(x[e] & 0xffff));
-      acc[2 * e + 1] += wj * DT::to_f32((uint16_t)(x[e] >> 16));
+      // (one fused multiply-add per term, spelled out: the projection that takes this sum in its prologue repeats it)
+      acc[2 * e] = __builtin_fmaf(wj, DT::to_f32((uint16_t)(x[e] & 0xffff)), acc[2 * e]);
+      acc[2 * e + 1] = __builtin_fmaf(wj, DT::to_f32((uint16_t)(x[e] >> 16)), acc[2 * e + 1]);
     }
   }
   u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; e++) o[e] = pack2<DT>(acc[2 * e], acc[2 * e + 1]);
+  for (int e = 0; e < 4; e++) {
+    // (the sums exist as fp32 values before they are rounded to 16 bits: no fused multiply-add-convert)
+    asm volatile("" : "+v"(acc[2 * e]), "+v"(acc[2 * e + 1]));
+    o[e] = pack2<DT>(acc[2 * e], acc[2 * e + 1]);
+  }
   *reinterpret_cast<u32x4*>(out + (size_t)t * H + 8 * v) = o;
 }
 

@@ -280,7 +280,9 @@ extern "C" int mi355q_w4a16_unpack_host(const void* packed, int32_t* q, int K, i
 // ---------------------------------------------------------------------------
 namespace mi355q {
 
-enum { PRO_NONE = 0, PRO_SILU = 1, PRO_ADDNORM = 2 };
+// PRO_MIXNORM (the one-workgroup-per-strip kernel only): PRO_ADDNORM whose input row is the weighted sum of a routed
+// layer's two selected expert outputs, x = round(w0 y0 + w1 y1) in fp32 in slot order -- the combine of moe_sum_kernel
+enum { PRO_NONE = 0, PRO_SILU = 1, PRO_ADDNORM = 2, PRO_MIXNORM = 3 };
 
 struct SkinnyParams {
   const uint16_t* x;       // [M, K]; PRO_SILU: [M, 2K] gate|up; PRO_ADDNORM: the un-normed input
@@ -720,6 +722,7 @@ struct BurstParams {
   long long wp_estride;   // u32x4 units between experts
   long long sc_estride;   // 16-bit elements between experts (scales and zc)
   unsigned long long* stamps;  // diagnostics: 4 x 100 MHz timestamps per workgroup, or null
+  const float* mix_w;          // PRO_MIXNORM: [M, 2] routing weights; x holds [M, 2, K] expert outputs (ldx = K)
 };
 
 static unsigned long long* g_burst_stamps = nullptr;
@@ -776,18 +779,25 @@ __global__ __launch_bounds__(burst_threads(NS, CPW)) void w4a16_burst_kernel(con
   // constant at the join and wait for ALL outstanding loads there -- before the weight burst below has
   // even been requested, which costs the kernel a whole memory round trip.
   const int vecs_row = p.K >> 3;
-  u32x4 xa[BURST_XV], xb[BURST_XV], xw[BURST_XV];
+  constexpr bool NORM = PRO == PRO_ADDNORM || PRO == PRO_MIXNORM;
+  u32x4 xa[BURST_XV], xb[BURST_XV], xw[BURST_XV], xm[PRO == PRO_MIXNORM ? BURST_XV : 1];
   const bool single = Mt == 1 && vecs_row <= BURST_XV * nthreads;
+  float mw0 = 0.f, mw1 = 0.f;
+  if constexpr (PRO == PRO_MIXNORM) {   // wave-uniform: scalar loads
+    mw0 = p.mix_w[2 * row0];
+    mw1 = p.mix_w[2 * row0 + 1];
+  }
   {
-    const uint16_t* xr = p.x + (size_t)xrow0 * p.ldx;
-    const uint16_t* rr = (PRO == PRO_ADDNORM && p.res_in) ? p.res_in + (size_t)row0 * p.K : xr;
-    const uint16_t* wr = (PRO == PRO_ADDNORM && p.norm_w) ? p.norm_w : xr;
+    const uint16_t* xr = p.x + (size_t)(PRO == PRO_MIXNORM ? 2 * xrow0 : xrow0) * p.ldx;
+    const uint16_t* rr = (NORM && p.res_in) ? p.res_in + (size_t)row0 * p.K : xr;
+    const uint16_t* wr = (NORM && p.norm_w) ? p.norm_w : xr;
 #pragma unroll
     for (int i = 0; i < BURST_XV; i++) {
       const int v = min((int)threadIdx.x + i * nthreads, vecs_row - 1);
       xa[i] = *reinterpret_cast<const u32x4*>(xr + 8 * v);
+      if constexpr (PRO == PRO_MIXNORM) xm[i] = *reinterpret_cast<const u32x4*>(xr + p.ldx + 8 * v);
       if constexpr (PRO == PRO_SILU) xb[i] = *reinterpret_cast<const u32x4*>(xr + p.K + 8 * v);
-      if constexpr (PRO == PRO_ADDNORM) {
+      if constexpr (NORM) {
         xb[i] = *reinterpret_cast<const u32x4*>(rr + 8 * v);
         xw[i] = *reinterpret_cast<const u32x4*>(wr + 8 * v);
       }
@@ -897,7 +907,7 @@ __global__ __launch_bounds__(burst_threads(NS, CPW)) void w4a16_burst_kernel(con
   auto lo = [](uint32_t u) { return DT::to_f32((uint16_t)(u & 0xffff)); };
   auto hi = [](uint32_t u) { return DT::to_f32((uint16_t)(u >> 16)); };
   if (single) {
-    if constexpr (PRO == PRO_ADDNORM) {
+    if constexpr (NORM) {
       float ss = 0.f;
 #pragma unroll
       for (int i = 0; i < BURST_XV; i++) {
@@ -905,6 +915,14 @@ __global__ __launch_bounds__(burst_threads(NS, CPW)) void w4a16_burst_kernel(con
         if (v < vecs_row) {
 #pragma unroll
           for (int e = 0; e < 4; e++) {
+            if constexpr (PRO == PRO_MIXNORM) {   // the routed layer's combine, as moe_sum_kernel does it
+              float m0 = __builtin_fmaf(mw1, lo(xm[i][e]), __builtin_fmaf(mw0, lo(xa[i][e]), 0.f));
+              float m1 = __builtin_fmaf(mw1, hi(xm[i][e]), __builtin_fmaf(mw0, hi(xa[i][e]), 0.f));
+              // the fp32 sums are rounded to fp32 first, as the stand-alone kernel's are: without this the compiler
+              // folds the last multiply-add and the conversion into one instruction with a single rounding (fp16)
+              asm volatile("" : "+v"(m0), "+v"(m1));
+              xa[i][e] = pack2<DT>(m0, m1);
+            }
             float a = lo(xa[i][e]), c = hi(xa[i][e]);
             if (p.res_in) {
               a = DT::to_f32(DT::from_f32(a + lo(xb[i][e])));
@@ -961,7 +979,7 @@ __global__ __launch_bounds__(burst_threads(NS, CPW)) void w4a16_burst_kernel(con
     for (int mb = 0; mb < Mt; mb += 4) {
       const int nm = min(4, Mt - mb);
       float rs[4] = {1.f, 1.f, 1.f, 1.f};
-      if constexpr (PRO == PRO_ADDNORM) {
+      if constexpr (NORM) {   // (PRO_MIXNORM never gets here: the host admits it for single rows only)
         float ss[4] = {0.f, 0.f, 0.f, 0.f};
         for (int v = threadIdx.x; v < vecs_row; v += nthreads) {
 #pragma unroll
@@ -1012,7 +1030,7 @@ __global__ __launch_bounds__(burst_threads(NS, CPW)) void w4a16_burst_kernel(con
             o[e] = pack2<DT>(s0 * lo(u[e]), s1 * hi(u[e]));
           }
         }
-        if constexpr (PRO == PRO_ADDNORM) {
+        if constexpr (NORM) {
           u32x4 rv = u32x4{0u, 0u, 0u, 0u}, wv = u32x4{0u, 0u, 0u, 0u}, zo;
           if (p.res_in) rv = *reinterpret_cast<const u32x4*>(p.res_in + off * p.K + 8 * v);
           if (p.norm_w) wv = *reinterpret_cast<const u32x4*>(p.norm_w + 8 * v);
@@ -1034,7 +1052,7 @@ __global__ __launch_bounds__(burst_threads(NS, CPW)) void w4a16_burst_kernel(con
         }
         *reinterpret_cast<u32x4*>(act + (size_t)(mb + m) * astride + 8 * v) = o;
       }
-      if constexpr (PRO == PRO_ADDNORM) __syncthreads();  // red is reused by the next row group
+      if constexpr (NORM) __syncthreads();  // red is reused by the next row group
     }
   }
   if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
@@ -2556,6 +2574,7 @@ struct NormArgs {
   void* res_out;
   const void* norm_w;
   float eps;
+  const float* mix_w = nullptr;   // PRO_MIXNORM: [M, 2] routing weights
 };
 
 struct MoeArgs {
@@ -2625,8 +2644,13 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
       b.x = (const uint16_t*)x; b.ldx = ldx; b.wp = (const u32x4*)packed;
       b.scales = (const uint16_t*)scales; b.zc = (const uint16_t*)zc; b.bias = (const uint16_t*)bias;
       b.out = (uint16_t*)c;
-      b.res_in = nullptr; b.res_out = nullptr; b.norm_w = nullptr; b.eps = 0.f;
-      if (pro == PRO_ADDNORM) {
+      b.res_in = nullptr; b.res_out = nullptr; b.norm_w = nullptr; b.eps = 0.f; b.mix_w = nullptr;
+      if (pro == PRO_MIXNORM) {
+        MI355Q_REQUIRE(na && na->mix_w && M == 1 && !moe && K / 8 <= BURST_XV * bp.nw * 64 && ldx == K,
+                       "w4a16_gemm_moe_sum_add_rms_norm: one token, rows of K <= %d channels", 8 * BURST_XV * bp.nw * 64);
+        b.mix_w = na->mix_w;
+      }
+      if (pro == PRO_ADDNORM || pro == PRO_MIXNORM) {
         MI355Q_REQUIRE(na && na->res_out, "w4a16_gemm_add_rms_norm: residual_out is required");
         MI355Q_REQUIRE(((uintptr_t)na->res_in & 15) == 0 && ((uintptr_t)na->res_out & 15) == 0 && ((uintptr_t)na->norm_w & 15) == 0,
                        "w4a16_gemm_add_rms_norm: pointers must be 16-byte aligned");
@@ -2643,6 +2667,7 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
   switch (pro) {                                                                               \
     case PRO_SILU: return launch_burst<DTT, PRO_SILU>(b, ns, bp.cpw, bp.lds, stream);          \
     case PRO_ADDNORM: return launch_burst<DTT, PRO_ADDNORM>(b, ns, bp.cpw, bp.lds, stream);    \
+    case PRO_MIXNORM: return launch_burst<DTT, PRO_MIXNORM>(b, ns, bp.cpw, bp.lds, stream);    \
     default: return launch_burst<DTT, PRO_NONE>(b, ns, bp.cpw, bp.lds, stream);                \
   }
       if (act_dtype == MI355Q_BF16) { MI355Q_BPRO(BF16) }
@@ -2652,6 +2677,7 @@ static int gemm_impl(const void* x, int ldx, const void* packed, const void* sca
   }
   MI355Q_REQUIRE(!epi_silu, "w4a16_gemm: the SiLU-pair epilogue needs a layer the burst kernel serves "
                             "(group size a multiple of 128, at least 128 strips)");
+  MI355Q_REQUIRE(pro != PRO_MIXNORM, "w4a16_gemm_moe_sum_add_rms_norm: layer shape not served by the one-workgroup-per-strip kernel");
   MI355Q_REQUIRE(legacy_kernel_ok(sw, K, G), "w4a16_gemm: strip width %d with group size %d needs K = 128 * waves * {2,4,7} and at least 128 strips", sw, G);
   const int CS = chunk_steps(G);
   SkinnyParams p;
@@ -2796,6 +2822,30 @@ extern "C" int mi355q_w4a16_gemm_add_rms_norm(const void* x, int ldx, const void
   NormArgs na{residual_in, residual_out, norm_weight, epsilon};
   return gemm_impl(x, ldx, packed, scales, zc, bias, c, M, N, K, G, tile, act_dtype, workspace,
                    workspace_bytes, split_k, (hipStream_t)stream, PRO_ADDNORM, &na);
+}
+
+extern "C" int mi355q_w4a16_gemm_moe_sum_add_rms_norm_supported(int num_tokens, int topk, int N, int K, int G, int tile) {
+  if (G <= 0) G = K;
+  if (num_tokens != 1 || topk != 2 || K <= 0 || N <= 0 || tile <= 0 || tile % 16 || N % tile || K % 128) return 0;
+  if (!tile_ok(tile, K, G)) return 0;
+  const BurstPlan bp = plan_burst(1, K, G, tile / 16, false);
+  const long blocks = N / tile;
+  return bp.ok && K / 8 <= BURST_XV * bp.nw * 64 && blocks >= env_int("MI355Q_SPLIT_BELOW", 64) ? 1 : 0;
+}
+
+extern "C" int mi355q_w4a16_gemm_moe_sum_add_rms_norm(const void* expert_out, const float* topk_weights, int topk,
+                                                       const void* residual_in, void* residual_out,
+                                                       const void* norm_weight, float epsilon, const void* packed,
+                                                       const void* scales, const void* zc, const void* bias, void* c,
+                                                       int num_tokens, int N, int K, int G, int tile, int act_dtype,
+                                                       mi355q_stream_t stream) {
+  MI355Q_REQUIRE(expert_out && topk_weights, "w4a16_gemm_moe_sum_add_rms_norm: null pointer");
+  MI355Q_REQUIRE(mi355q_w4a16_gemm_moe_sum_add_rms_norm_supported(num_tokens, topk, N, K, G, tile),
+                 "w4a16_gemm_moe_sum_add_rms_norm: one token, two selected experts, a layer the one-workgroup-per-strip "
+                 "kernel serves (tokens %d, top-%d, %d x %d)", num_tokens, topk, K, N);
+  NormArgs na{residual_in, residual_out, norm_weight, epsilon, topk_weights};
+  return gemm_impl(expert_out, K, packed, scales, zc, bias, c, num_tokens, N, K, G, tile, act_dtype, nullptr, 0, 1,
+                   (hipStream_t)stream, PRO_MIXNORM, &na);
 }
 
 extern "C" int mi355q_w4a16_dequantize(const void* packed, const void* scales, const void* zc,

@@ -40,6 +40,9 @@ _SIGS = {
     "mi355q_workspace_init": (c_int, [c_vp, c_sz, c_vp]),
     "mi355q_w4a16_gemm_add_rms_norm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_int, c_vp]),
+    "mi355q_w4a16_gemm_moe_sum_add_rms_norm_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mi355q_w4a16_gemm_moe_sum_add_rms_norm": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                                       c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "mi355q_w4a16_gemm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_vp, c_sz, c_int, c_vp]),
     "mi355q_w4a16_gemm_silu_mul": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int,

@@ -41,6 +41,8 @@ class LlamaConfig:
 FUSE_NORM_MAX_TOKENS = int(os.environ.get("MI355Q_FUSE_NORM_MAX", "1"))
 # up to this many tokens the MoE router runs norm, gate projection and top-k as one launch (one workgroup per token)
 ROUTER_FUSED_MAX_TOKENS = int(os.environ.get("MI355Q_ROUTER_FUSED_MAX", "16"))
+# a routed layer's weighted sum in the prologue of the next layer's qkv projection (one token, top-2)
+DEFER_MOE_SUM = os.environ.get("MI355Q_DEFER_MOE_SUM", "1") != "0"
 
 CONFIGS = {
     "llama3-8b": LlamaConfig("llama3-8b", 4096, 14336, 32, 32, 8, 128, 128256),
@@ -194,6 +196,22 @@ class Linear16:
         return torch.nn.functional.linear(x, self.weight)
 
 
+class ExpertRows:
+    """A routed layer's output before its combine: the selected experts' rows [T, topk, H] and their fp32 weights.
+    The next layer's qkv projection takes the weighted sum in its prologue (one token, top-2); anything else
+    asks for the sum."""
+
+    def __init__(self, rows: torch.Tensor, weights: torch.Tensor):
+        self.rows, self.weights = rows, weights
+        self.shape = (rows.shape[0], rows.shape[2])
+        self.dtype, self.device = rows.dtype, rows.device
+
+    def sum(self) -> torch.Tensor:
+        out = torch.empty(self.shape, dtype=self.dtype, device=self.device)
+        ops.moe_sum(self.rows, out, self.weights)
+        return out
+
+
 class MoeBlock:
     """Routed experts of one decoder layer: a 16-bit router [E, H] and 4-bit experts generated directly in
     the layout the MoE WNA16 loader leaves them in (moe_wna16.py:516-638): w13 uint8 [E, 2I, H/2] (gate rows,
@@ -231,13 +249,15 @@ class MoeBlock:
             self.checkpoint = (cpu(w13), cpu(w2))
 
     def __call__(self, x: torch.Tensor, residual: torch.Tensor | None = None, norm_weight: torch.Tensor | None = None,
-                 eps: float = 0.0) -> torch.Tensor:
+                 eps: float = 0.0, combine: bool = True):
         """With `residual`: x is the attention block's output, and the post-attention add + norm runs here (in
-        place on both, inside the router's launch at decode sizes)."""
+        place on both, inside the router's launch at decode sizes).  combine=False: ExpertRows instead of the sum."""
         from .plugin.moe import fused_experts, fused_topk
         T = x.shape[0]
         if residual is not None and T <= ROUTER_FUSED_MAX_TOKENS and ops.moe_router_topk_supported(*self.router.shape):
             w, ids = ops.moe_router_topk(x, residual, norm_weight, eps, self.router, self.top_k, True)
+            if not combine:
+                return ExpertRows(fused_experts(x, self.w13, self.w2, w, ids, combine=False), w)
             return fused_experts(x, self.w13, self.w2, w, ids)
         if residual is not None:
             ops.fused_add_rms_norm(x, residual, norm_weight, eps)
@@ -398,6 +418,12 @@ class LlamaRunner:
         T = h.shape[0]
         # small token counts: the add+RMSNorm runs in the prologue of the GEMM that consumes it
         fuse_norm = self.quant != "none" and T <= FUSE_NORM_MAX_TOKENS
+        mixed = None
+        if isinstance(h, ExpertRows):   # the previous layer's experts, not combined yet
+            if fuse_norm and attend is None and ops.w4a16_gemm_moe_sum_add_rms_norm_supported(T, h.rows.shape[1], L["qkv"].w):
+                mixed = h
+            else:
+                h = h.sum()
         # prompt tokens on the tiled kernel: projection, RoPE and cache write as one op
         qkv_tail = (attend is not None and self.quant != "none" and ops.MM_MIN_TOKENS <= T <= ops.MM_MAX_TOKENS
                     and ops._mm_supported(L["qkv"].w))
@@ -409,7 +435,10 @@ class LlamaRunner:
                                                    self.k_scale, self.v_scale)
             return L["qkv"](x)
 
-        if normed:
+        if mixed is not None:   # combine, residual add, norm and projection in one launch
+            qkv, residual = ops.w4a16_gemm_moe_sum_add_rms_norm(mixed.rows, mixed.weights, residual, L["ln1"], cfg.rms_eps,
+                                                                L["qkv"].w)
+        elif normed:
             qkv = qkv_proj(h)
         elif fuse_norm:
             qkv, residual = ops.w4a16_gemm_add_rms_norm(h, residual, L["ln1"], cfg.rms_eps, L["qkv"].w)
@@ -444,7 +473,10 @@ class LlamaRunner:
         if "moe" in L:   # router, top-k, experts, weighted sum (mixtral.py:126-130); all-reduce of the partial sums
             if o_normed:
                 return self._all_reduce(L["moe"](o)), residual, False
-            return self._all_reduce(L["moe"](o, residual, L["ln2"], cfg.rms_eps)), residual, False
+            # one token, no tensor parallelism: the combine is left to the next layer's qkv projection
+            defer = fuse_norm and attend is None and not self.tp_collectives and next_norm is not None and DEFER_MOE_SUM
+            out = L["moe"](o, residual, L["ln2"], cfg.rms_eps, combine=not defer)
+            return (out if isinstance(out, ExpertRows) else self._all_reduce(out)), residual, False
         tail = next_norm is not None and self._tail_norm_ok(T, L["down"]) if self.quant != "none" else False
 
         def down(act, **kw):
@@ -489,6 +521,8 @@ class LlamaRunner:
         return self.layers[li + 1]["ln1"] if li + 1 < len(self.layers) else self.norm
 
     def _logits(self, h, residual, normed=False):
+        if isinstance(h, ExpertRows):
+            h = h.sum()
         if not normed:
             ops.fused_add_rms_norm(h, residual, self.norm, self.cfg.rms_eps)
         M = h.shape[0]

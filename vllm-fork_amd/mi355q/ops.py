@@ -301,6 +301,33 @@ def w4a16_gemm_add_rms_norm(x: torch.Tensor, residual: torch.Tensor | None, norm
     return out.reshape(x.shape[:-1] + (w.N,)), res_out.reshape(x.shape)
 
 
+def w4a16_gemm_moe_sum_add_rms_norm_supported(num_tokens: int, topk: int, w: PackedW4) -> bool:
+    return bool(_lib.lib().mi355q_w4a16_gemm_moe_sum_add_rms_norm_supported(num_tokens, topk, w.N, w.K, w.G, w.tile))
+
+
+def w4a16_gemm_moe_sum_add_rms_norm(expert_out: torch.Tensor, topk_weights: torch.Tensor, residual: torch.Tensor,
+                                    norm_weight: torch.Tensor | None, epsilon: float, w: PackedW4,
+                                    bias: torch.Tensor | None = None):
+    """moe_sum(expert_out, topk_weights) -> fused_add_rms_norm(., residual) -> W4A16 GEMM as one kernel: expert_out
+    [1, 2, K] (the selected experts' outputs of one token), topk_weights fp32 [1, 2].  Returns (gemm output [1, N],
+    new residual [1, K]) with the bits of the three ops run one after the other."""
+    _need_cuda(expert_out, topk_weights, w.packed)
+    if expert_out.dim() != 3 or expert_out.shape[2] != w.K or not expert_out.is_contiguous():
+        raise RuntimeError(f"expert_out must be a contiguous [tokens, topk, {w.K}] tensor")
+    T, topk = expert_out.shape[0], expert_out.shape[1]
+    if topk_weights.dtype != torch.float32 or tuple(topk_weights.shape) != (T, topk) or not topk_weights.is_contiguous():
+        raise RuntimeError("topk_weights must be a contiguous fp32 [tokens, topk] tensor")
+    if residual is None or not residual.is_contiguous() or residual.numel() != T * w.K:
+        raise RuntimeError("residual must be a contiguous [tokens, hidden] tensor")
+    out = torch.empty((T, w.N), dtype=expert_out.dtype, device=expert_out.device)
+    res_out = torch.empty((T, w.K), dtype=expert_out.dtype, device=expert_out.device)
+    check(_lib.lib().mi355q_w4a16_gemm_moe_sum_add_rms_norm(
+        expert_out.data_ptr(), topk_weights.data_ptr(), topk, residual.data_ptr(), res_out.data_ptr(), _ptr(norm_weight),
+        epsilon, w.packed.data_ptr(), w.scales.data_ptr(), _ptr(w.zc), _ptr(bias), out.data_ptr(), T, w.N, w.K, w.G,
+        w.tile, _dt(expert_out), _stream()))
+    return out, res_out
+
+
 def w4a16_gate_up_silu(x: torch.Tensor, residual: torch.Tensor | None, norm_weight: torch.Tensor | None,
                        epsilon: float, w: PackedW4, add_norm: bool = True):
     """[fused_add_rms_norm ->] gate_up projection -> SiluAndMul in one kernel, for a weight repacked with

@@ -223,7 +223,9 @@ def fused_topk(gating_output: torch.Tensor, topk: int, renormalize: bool):
 
 
 def fused_experts(x: torch.Tensor, w13: ops.PackedMoeW4, w2: ops.PackedMoeW4, topk_weights: torch.Tensor,
-                  topk_ids: torch.Tensor, expert_map: torch.Tensor | None = None) -> torch.Tensor:
+                  topk_ids: torch.Tensor, expert_map: torch.Tensor | None = None, combine: bool = True) -> torch.Tensor:
+    """combine=False: the selected experts' outputs [T, topk, H] without the weighted sum (a caller that folds the
+    sum into its next kernel)."""
     T, H = x.shape
     topk = topk_ids.shape[1]
     ids = topk_ids.reshape(-1)
@@ -304,6 +306,8 @@ def fused_experts(x: torch.Tensor, w13: ops.PackedMoeW4, w2: ops.PackedMoeW4, to
             act = torch.empty((h.shape[0], h.shape[1] // 2), dtype=x.dtype, device=x.device)
             ops.silu_and_mul(act, h)
             y.index_copy_(0, rows, torch.matmul(act, ops.w4a16_dequantize(w2.expert(e))))
+    if not combine:
+        return y.view(T, topk, H)
     out = torch.empty((T, H), dtype=x.dtype, device=x.device)
     ops.moe_sum(y.view(T, topk, H), out, topk_weights.contiguous())
     return out
