@@ -265,7 +265,7 @@ static int launch_linear(const void* a, int lda, const void* w, const void* bias
   // rows that do not fit in half a CU's LDS with their whole K: phases of K, two workgroups per CU.  (The lm_head
   // of Llama-3-8B, 128256 x 4096: 8 rows unphased 187 us; 16 rows 210 us, against 385 us as two passes of 8 rows
   // over the weight; 32 rows 231 us.)
-  if (K % 256 == 0 && (M > 16 || (size_t)M * (K + 8) * 2 > 80 * 1024) && !env_flag("MI355Q_LINEAR_NO_MFMA")) {
+  if (M >= 3 && K % 256 == 0 && (M > 16 || (size_t)M * (K + 8) * 2 > 80 * 1024) && !env_flag("MI355Q_LINEAR_NO_MFMA")) {
     const int rb = M > 16 ? 2 : 1;
     const int kp = std::min(K, env_int("MI355Q_LINEAR_KP", rb == 2 ? 1024 : 2048));
     MI355Q_REQUIRE(kp >= 256 && kp % 256 == 0 && (size_t)16 * rb * (kp + 8) * 2 <= 150 * 1024, "linear_skinny: bad phase length %d", kp);
@@ -279,7 +279,9 @@ static int launch_linear(const void* a, int lda, const void* w, const void* bias
                          (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)c, M, N, K, kp);
     return check_launch("linear_mfma_phases_kernel");
   }
-  if (M >= 2 && K % 32 == 0 && !env_flag("MI355Q_LINEAR_NO_MFMA")) {
+  // two rows still go on the dot-product kernel (lm_head of Llama-3-8B: 172 us against 187 on the matrix cores; from
+  // four rows on its vector work shows: 186 / 187, 346 at eight)
+  if (M >= 3 && K % 32 == 0 && !env_flag("MI355Q_LINEAR_NO_MFMA")) {
     int rows_pp = std::min(M, 16);
     while (rows_pp > 1 && (size_t)rows_pp * (K + 8) * 2 > 144 * 1024) rows_pp--;
     const size_t lds_m = (size_t)rows_pp * (K + 8) * 2;
