@@ -9,7 +9,8 @@ L.mi355q_debug_attention_stamps.argtypes = [ctypes.c_void_p]; L.mi355q_debug_att
 cfg = CONFIGS["llama3-8b"]
 import dataclasses
 cfg = dataclasses.replace(cfg, layers=4)
-r = LlamaRunner(cfg, quant="gptq", device="cuda:0", max_batch=1, max_seq_len=256)
+KV = sys.argv[1] if len(sys.argv) > 1 else "auto"     # "auto" (16-bit cache) or "fp8"
+r = LlamaRunner(cfg, quant="gptq", kv_cache_dtype=KV, device="cuda:0", max_batch=1, max_seq_len=256)
 r.reset(200)
 for _ in range(3): r._decode_body()
 st = torch.zeros((64, 10), dtype=torch.int64, device="cuda:0")

@@ -88,18 +88,20 @@ int reset_attention_state(hipStream_t stream) {
   return check_launch("pa_reset_kernel");
 }
 
+// four e4m3 bytes -> four 16-bit values.  Every e4m3 value (subnormals included) is a bf16 and an fp16 value, so the
+// conversion is exact; gfx950 converts a pair straight to the 16-bit type (v_cvt_scalef32_pk_{bf16,f16}_fp8 with a
+// unit scale): two instructions per word instead of two conversions to fp32 and the repacking of four words.
+typedef __attribute__((ext_vector_type(2))) __bf16 pa_bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 pa_f16x2;
 template <typename DT>
 __device__ inline u32x2 fp8x4_to_h16(uint32_t v) {
-  const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(v, false);
-  const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8(v, true);
   u32x2 r;
   if constexpr (DT::id == MI355Q_BF16) {
-    // every e4m3 value is a bf16 value: the upper halves of the fp32 words are the result
-    r[0] = (__float_as_uint(lo[0]) >> 16) | (__float_as_uint(lo[1]) & 0xffff0000u);
-    r[1] = (__float_as_uint(hi[0]) >> 16) | (__float_as_uint(hi[1]) & 0xffff0000u);
+    r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, false));
+    r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, true));
   } else {
-    r[0] = pack2<DT>(lo[0], lo[1]);
-    r[1] = pack2<DT>(hi[0], hi[1]);
+    r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v, 1.0f, false));
+    r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v, 1.0f, true));
   }
   return r;
 }
@@ -903,10 +905,9 @@ __global__ __launch_bounds__(256, 2) void decode_step_kernel(const PAParams p) {
   const bool owns_new = tl >= 0 && tl < 64;
   const int Tn = tl >> 4, cn = tl & 15;
   uint32_t vnew[DTILES];                  // the value's cache form, one element per head-dim tile
+  if constexpr (!KVFP8) {
 #pragma unroll
-  for (int dt = 0; dt < DTILES; dt++) {
-    if constexpr (!KVFP8) vnew[dt] = vn[dt];
-    else vnew[dt] = f32_to_fp8(DT::to_f32(vn[dt]) / vscale);
+    for (int dt = 0; dt < DTILES; dt++) vnew[dt] = vn[dt];
   }
   if (owns_new) {
     u32x4 knew[KR];                       // the key's cache form
@@ -914,16 +915,45 @@ __global__ __launch_bounds__(256, 2) void decode_step_kernel(const PAParams p) {
 #pragma unroll
       for (int ds = 0; ds < DS; ds++) knew[ds] = kf[ds];
     } else {
+      // value / scale is a true division (the arithmetic of the cache-write kernel), a dozen instructions each, and
+      // this wave stands between every wave of the workgroup and the softmax barrier: the 16 lanes of a kq row hold
+      // the same 32 key values and the 4 lanes of a column the same 8 value elements, so every lane quantises one
+      // dword of the key (4 values) and two elements of the value instead of all 40, and the rows / columns exchange
+      // the results (6 divisions per lane instead of 40)
       auto enc4 = [&](uint32_t lo, uint32_t hi) {   // four 16-bit values -> four e4m3 bytes of value / k_scale
         const float a = DT::to_f32((uint16_t)(lo & 0xffff)) / kscale, b = DT::to_f32((uint16_t)(lo >> 16)) / kscale;
         const float c = DT::to_f32((uint16_t)(hi & 0xffff)) / kscale, d = DT::to_f32((uint16_t)(hi >> 16)) / kscale;
         return (uint32_t)f32_to_fp8(a) | ((uint32_t)f32_to_fp8(b) << 8) | ((uint32_t)f32_to_fp8(c) << 16) |
                ((uint32_t)f32_to_fp8(d) << 24);
       };
+      static_assert(DS == 4 && DTILES == 8, "the exchange below is laid out for head size 128");
+      // dword j = 4 sp + e of the key's 32 bytes comes from fragment 2 sp + (e >> 1), words 2 (e & 1) and 2 (e & 1) + 1
+      const int j = col & 7, jf = 2 * (j >> 2) + ((j >> 1) & 1), jh = j & 1;
+      uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+      for (int f = 0; f < DS; f++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const bool m = jf == f && jh == h;
+          lo = m ? kf[f][2 * h] : lo;
+          hi = m ? kf[f][2 * h + 1] : hi;
+        }
+      const uint32_t kmine = enc4(lo, hi);
 #pragma unroll
       for (int sp = 0; sp < DS / 2; sp++)
-        knew[sp] = u32x4{enc4(kf[2 * sp][0], kf[2 * sp][1]), enc4(kf[2 * sp][2], kf[2 * sp][3]),
-                         enc4(kf[2 * sp + 1][0], kf[2 * sp + 1][1]), enc4(kf[2 * sp + 1][2], kf[2 * sp + 1][3])};
+#pragma unroll
+        for (int e = 0; e < 4; e++) knew[sp][e] = (uint32_t)__shfl((int)kmine, (lane & 48) | (4 * sp + e), 64);
+      // value elements 2 kq and 2 kq + 1 of this column
+      uint32_t v0 = 0u, v1 = 0u;
+#pragma unroll
+      for (int dt = 0; dt < DTILES; dt++) {
+        v0 = dt == 2 * kq ? vn[dt] : v0;
+        v1 = dt == 2 * kq + 1 ? vn[dt] : v1;
+      }
+      const uint32_t q0 = f32_to_fp8(DT::to_f32((uint16_t)v0) / vscale), q1 = f32_to_fp8(DT::to_f32((uint16_t)v1) / vscale);
+#pragma unroll
+      for (int dt = 0; dt < DTILES; dt++)
+        vnew[dt] = (uint32_t)__shfl((int)((dt & 1) ? q1 : q0), ((dt >> 1) << 4) | col, 64);
     }
     // cache append: the block is this wave's entry of the tile
     const int blk = Tn == 0 ? ent[0] : (Tn == 1 ? ent[1] : (Tn == 2 ? ent[2] : ent[3]));
