@@ -2178,15 +2178,17 @@ __global__ __launch_bounds__(512, 1) void w4a16_mm_ring_kernel(const MmParams p)
 // kernel re-reads every strip per 32-row block and needs K-slices plus a second kernel to fill the
 // chip, which costs 2-3x the streaming time at these sizes.  The activation rows do not fit in LDS
 // (32 rows x K), so every lane reads its own MFMA operand fragments straight from global memory (L2
-// resident: M x K x 2 bytes), one chunk ahead.  The per-chunk fp32 results tot += s (acc - (bias + z)
+// resident: M x K x 2 bytes), one chunk ahead (XLDS: whole rows, turned into fragments through LDS,
+// see below).  The per-chunk fp32 results tot += s (acc - (bias + z)
 // acc1) are accumulated in the wave's own slice of LDS instead of registers (two accumulator sets per
 // row tile do not fit beside the weight ring and the activation fragments at two waves per SIMD); the
 // slices are summed across waves at the end.  Same arithmetic and rounding as the other kernels.
 // ---------------------------------------------------------------------------
 // REGACC: the running sums stay in registers (the per-chunk read-modify-write of the LDS slice is gone; same
 // operations in the same order, so the same bits) -- where ring, fragments and two sets of sums fit in 256 registers.
-template <typename DT, int NS, int CPW, bool HAS_ZC, bool REGACC = false>
+template <typename DT, int NS, int CPW, bool HAS_ZC, bool REGACC = false, bool XLDS = false>
 __global__ __launch_bounds__(512) void w4a16_stream_rows_kernel(const MmParams p, int bursts) {
+  static_assert(!XLDS || REGACC, "the staging areas lie over the slices of the final sum");
   constexpr int SW = 16 * NS, QW = 4 * NS, RT = 2, NW = 8;
   extern __shared__ __attribute__((aligned(16))) float red[];   // [NW][32][SW]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2208,16 +2210,54 @@ __global__ __launch_bounds__(512) void w4a16_stream_rows_kernel(const MmParams p
 #pragma unroll
     for (int pl = 0; pl < NS; pl++) w[i][pl] = __builtin_nontemporal_load(wstrip + (c * NS + pl) * 64);
   };
+  // The activation chunk [32 rows][256 B] of a wave.  Fetched as operand fragments, one wave instruction gathers
+  // 64-byte pieces of 16 rows and occupies the address path about four times as long as one that reads whole rows
+  // (measured: the second row tile of a 32-row pass cost gate_up 3.5 us and qkv 3.1 us; a tile of one distinct
+  // row costs next to nothing).  XLDS: the rows are fetched whole (4 rows x 256 B per instruction), written to the
+  // wave's own 8 KiB of LDS (piece p of row r at position p ^ (r & 15): conflict-free both ways) and read back as
+  // fragments -- same values in the same lanes.  The staging areas lie over the slices of the final sum, which the
+  // running sums in registers leave unused until the end.  It pays when the second row tile is mostly real rows
+  // (us at 17 / 24 / 32 rows, gathered -> staged: qkv 9.2 / 10.4 / 12.3 -> 10.4 / 10.6 / 10.9, gate_up 16.5 / 18.2 /
+  // 20.0 -> 18.5 / 17.9 / 19.0).
+  unsigned char* xst = reinterpret_cast<unsigned char*>(red) + wave * 8192;
+  const unsigned char* xbytes = reinterpret_cast<const unsigned char*>(p.x);
+  uint32_t xoff[8];   // byte offset of piece ml of row 4 t + kq
+#pragma unroll
+  for (int t = 0; t < 8; t++) xoff[t] = (uint32_t)min(row0 + 4 * t + kq, p.M - 1) * (uint32_t)(2 * p.ldx) + 16u * ml;
   auto load_x = [&](int c, u32x4 (&xf)[4][RT]) {
 #pragma unroll
     for (int ks = 0; ks < 4; ks++)
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++) xf[ks][rt] = *reinterpret_cast<const u32x4*>(xr[rt] + (size_t)c * 128 + 32 * ks);
+      for (int rt = 0; rt < RT; rt++) {
+        if constexpr (XLDS) xf[ks][rt] = *reinterpret_cast<const u32x4*>(xbytes + xoff[2 * ks + rt] + (size_t)c * 256);
+        else xf[ks][rt] = *reinterpret_cast<const u32x4*>(xr[rt] + (size_t)c * 128 + 32 * ks);
+      }
   };
-  u32x4 xc[4][RT], xn[4][RT];
-  load_x(cfirst, xc);
+  // rows as fetched -> the wave's staging area (fragments are read from there one k-step ahead of their use);
+  // gathered fragments are used as they are
+  auto stage_rows = [&](const u32x4 (&xrow)[4][RT]) {
 #pragma unroll
-  for (int i = 0; i < CPW; i++) issue_chunk(0, i);
+    for (int t = 0; t < 8; t++) {
+      const int r = 4 * t + kq;
+      *reinterpret_cast<u32x4*>(xst + r * 256 + 16 * (ml ^ (r & 15))) = xrow[t >> 1][t & 1];
+    }
+  };
+  auto read_fragments = [&](int ks, u32x4 (&xf)[RT]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+      xf[rt] = *reinterpret_cast<const u32x4*>(xst + (16 * rt + ml) * 256 + 16 * ((4 * ks + kq) ^ ml));
+  };
+  u32x4 xc[XLDS ? 1 : 4][RT], xn[4][RT];
+  if constexpr (XLDS) {
+    load_x(cfirst, xn);
+#pragma unroll
+    for (int i = 0; i < CPW; i++) issue_chunk(0, i);
+    stage_rows(xn);
+  } else {
+    load_x(cfirst, xc);
+#pragma unroll
+    for (int i = 0; i < CPW; i++) issue_chunk(0, i);
+  }
 
   const u32x4 ones = u32x4{DT::ones, DT::ones, DT::ones, DT::ones};
   // (x & mask) | magic in one instruction per 16-bit pair, constants in registers as in the tiled kernel below
@@ -2258,61 +2298,84 @@ __global__ __launch_bounds__(512) void w4a16_stream_rows_kernel(const MmParams p
       }
       load_x(min(c + 1, last), xn);
       __builtin_amdgcn_sched_barrier(0);
-      f32x4 acc[RT][NS], acc1[RT];
+      // With the fragments in LDS a 112-wide strip is taken in two passes over the chunk (subtiles 0-3, then 4-6):
+      // 8 instead of 14 accumulators per chunk are live beside the running sums, and the fragments are cheap to read
+      // twice.  Every accumulator still sums its k-steps in the same order.
+      constexpr int NH = (XLDS && NS == 7) ? 2 : 1, HS = NH == 2 ? 4 : NS;
+      f32x4 acc1[RT];
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++) {
-        acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rt = 0; rt < RT; rt++) acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sub = 0; sub < NS; sub++) acc[rt][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int h = 0; h < NH; h++) {
+        const int s0 = h * HS;
+        f32x4 acc[RT][HS];
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
+        for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) acc1[rt] = mfma16<DT>(ones, xc[ks][rt], acc1[rt]);
+          for (int sl = 0; sl < HS; sl++) acc[rt][sl] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 xf[2][RT];
+        if constexpr (XLDS) read_fragments(0, xf[0]);
 #pragma unroll
-        for (int sub = 0; sub < NS; sub++) {
-          const int e = ks * NS + sub;
-          const u32x4 wf = expand(w[i][e >> 2][e & 3]);
+        for (int ks = 0; ks < 4; ks++) {
+          if constexpr (XLDS) { if (ks < 3) read_fragments(ks + 1, xf[(ks + 1) & 1]); }
+          u32x4 (&xk)[RT] = XLDS ? xf[ks & 1] : xc[XLDS ? 0 : ks];
+          if (h == 0) {
 #pragma unroll
-          for (int rt = 0; rt < RT; rt++) acc[rt][sub] = mfma16<DT>(wf, xc[ks][rt], acc[rt][sub]);
+            for (int rt = 0; rt < RT; rt++) acc1[rt] = mfma16<DT>(ones, xk[rt], acc1[rt]);
+          }
+#pragma unroll
+          for (int sl = 0; sl < HS; sl++) {
+            if (s0 + sl >= NS) continue;
+            const int e = ks * NS + s0 + sl;
+            const u32x4 wf = expand(w[i][e >> 2][e & 3]);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) acc[rt][sl] = mfma16<DT>(wf, xk[rt], acc[rt][sl]);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // dequantised fragments of one k-step live at a time
         }
-        __builtin_amdgcn_sched_barrier(0);  // dequantised fragments of one k-step live at a time
-      }
-      // the slot just consumed is refilled at once
-      if (burst + 1 < bursts) issue_chunk(burst + 1, i);
-      // lane (kq, ml): rows 16 rt + ml, channels QW kq + 4 sub + r of the strip
+        // the slot just consumed is refilled at once
+        if (h == NH - 1 && burst + 1 < bursts) issue_chunk(burst + 1, i);
+        // lane (kq, ml): rows 16 rt + ml, channels QW kq + 4 sub + r of the strip
 #pragma unroll
-      for (int sub = 0; sub < NS; sub++) {
-        f32x4 sc, zz;
+        for (int sl = 0; sl < HS; sl++) {
+          if (s0 + sl >= NS) continue;
+          const int sub = s0 + sl;
+          f32x4 sc, zz;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          sc[r] = (r & 1) ? hi(sv[sub][r >> 1]) : lo(sv[sub][r >> 1]);
-          if constexpr (HAS_ZC) zz[r] = (r & 1) ? hi(zv[sub][r >> 1]) : lo(zv[sub][r >> 1]);
-          else zz[r] = DT::int4_bias + 8.0f;
-        }
+          for (int r = 0; r < 4; r++) {
+            sc[r] = (r & 1) ? hi(sv[sub][r >> 1]) : lo(sv[sub][r >> 1]);
+            if constexpr (HAS_ZC) zz[r] = (r & 1) ? hi(zv[sub][r >> 1]) : lo(zv[sub][r >> 1]);
+            else zz[r] = DT::int4_bias + 8.0f;
+          }
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
-          if constexpr (REGACC) {
+          for (int rt = 0; rt < RT; rt++) {
+            if constexpr (REGACC) {
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-              tot[rt][sub][r] = __builtin_fmaf(sc[r], __builtin_fmaf(-zz[r], acc1[rt][r], acc[rt][sub][r]), tot[rt][sub][r]);
-          } else {
-            f32x4* dst = reinterpret_cast<f32x4*>(mine + 16 * rt * SW + 4 * sub);
-            f32x4 t = (burst == 0 && i == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : *dst;
+              for (int r = 0; r < 4; r++)
+                tot[rt][sub][r] = __builtin_fmaf(sc[r], __builtin_fmaf(-zz[r], acc1[rt][r], acc[rt][sl][r]), tot[rt][sub][r]);
+            } else {
+              f32x4* dst = reinterpret_cast<f32x4*>(mine + 16 * rt * SW + 4 * sub);
+              f32x4 t = (burst == 0 && i == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : *dst;
 #pragma unroll
-            for (int r = 0; r < 4; r++) t[r] = __builtin_fmaf(sc[r], __builtin_fmaf(-zz[r], acc1[rt][r], acc[rt][sub][r]), t[r]);
-            *dst = t;
+              for (int r = 0; r < 4; r++) t[r] = __builtin_fmaf(sc[r], __builtin_fmaf(-zz[r], acc1[rt][r], acc[rt][sl][r]), t[r]);
+              *dst = t;
+            }
           }
         }
       }
+      if constexpr (XLDS) {
+        stage_rows(xn);
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++)
+        for (int ks = 0; ks < 4; ks++)
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) xc[ks][rt] = xn[ks][rt];
+          for (int rt = 0; rt < RT; rt++) xc[ks][rt] = xn[ks][rt];
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   if constexpr (REGACC) {
+    if constexpr (XLDS) __syncthreads();   // the slices lie over the staging areas: every wave has read its last fragments
 #pragma unroll
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
@@ -2344,6 +2407,7 @@ struct StreamRowsPlan {
   int ns, cpw, bursts;
   size_t lds;
   bool regacc;
+  bool xlds;   // activation rows fetched whole and turned into fragments through LDS (register-sum kernels only)
 };
 
 // rows 17..32, strips that alone occupy the chip, K that eight waves divide.  The kernel itself takes up to 64
@@ -2351,7 +2415,7 @@ struct StreamRowsPlan {
 // tiled kernel reads them once and wins: gate_up at 64 rows 42.0 -> 33.0 us, qkv 23.0 -> 19.5; whole decode step
 // at batch 48 4.27 -> 3.80 ms, batch 64 4.82 -> 4.29 ms.
 static StreamRowsPlan plan_stream_rows(int M, int N, int K, int G, int sw) {
-  StreamRowsPlan sp{false, 0, 0, 0, 0, false};
+  StreamRowsPlan sp{false, 0, 0, 0, 0, false, false};
   const int max_rows = env_int("MI355Q_STREAM_ROWS_MAX", 32);   // looked up per call: mi355q_set_option switches it
   if (M < 17 || M > max_rows || G % 128 || K % 128 || sw % 16 || N % sw) return sp;
   const int ns = sw / 16, chunks = K / 128;
@@ -2368,13 +2432,20 @@ static StreamRowsPlan plan_stream_rows(int M, int N, int K, int G, int sw) {
   // move (12.2 us: bound by the activation fragments every workgroup reads from L2, 5 x its weights).
   // MI355Q_STREAM_ROWS_REGACC = 0 keeps the sums in LDS, 1 leaves 112-wide strips on the two-chunk ring.
   const int regacc = env_int("MI355Q_STREAM_ROWS_REGACC", 2);
+  // whole-row activation fetch from 25 rows on (looked up per call)
+  const bool want_xlds = M >= env_int("MI355Q_STREAM_ROWS_XLDS_MIN", 25);
   const int cands[5] = {8, 7, 4, 2, 1};
   for (int cpw : cands) {
     if (per % cpw || cpw * ns > 16 || !stream_rows_built(ns, cpw)) continue;
+    // a four-chunk ring beside the whole-row fetch spills registers (qkv at 32 rows: 10.9 us, 9.3 with two chunks)
+    if (want_xlds && regacc >= 1 && ns == 2 && cpw > 2) continue;
     if (regacc == 2 && ns == 7 && cpw != 1) continue;
     sp.regacc = (regacc >= 1 && ns == 2) || (regacc == 2 && ns == 7 && cpw == 1);
     sp.ok = true; sp.ns = ns; sp.cpw = cpw; sp.bursts = per / cpw;
-    sp.lds = (size_t)8 * 32 * sw * sizeof(float);
+    // the eight 8 KiB staging areas lie over the slices
+    sp.xlds = sp.regacc && want_xlds;
+    const size_t slices = (size_t)8 * 32 * sw * sizeof(float), staging = (size_t)8 * 8192;
+    sp.lds = sp.xlds && staging > slices ? staging : slices;
     return sp;
   }
   return sp;
@@ -2391,8 +2462,17 @@ static int launch_stream_rows(const MmParams& p, const StreamRowsPlan& sp, hipSt
   }
 #define MI355Q_SRR(NS_, CPW_)                                                                                            \
   if (sp.regacc && sp.ns == NS_ && sp.cpw == CPW_) {                                                                     \
-    if (p.zc) hipLaunchKernelGGL((w4a16_stream_rows_kernel<DT, NS_, CPW_, true, true>), grid, block, sp.lds, stream, p, sp.bursts);  \
-    else hipLaunchKernelGGL((w4a16_stream_rows_kernel<DT, NS_, CPW_, false, true>), grid, block, sp.lds, stream, p, sp.bursts);      \
+    if (sp.xlds) {                                                                                                       \
+      if constexpr (NS_ * CPW_ <= 7) { /* the plan never pairs it with a longer ring */                                  \
+        if (p.zc) hipLaunchKernelGGL((w4a16_stream_rows_kernel<DT, NS_, CPW_, true, true, true>), grid, block, sp.lds, stream, p, sp.bursts);  \
+        else hipLaunchKernelGGL((w4a16_stream_rows_kernel<DT, NS_, CPW_, false, true, true>), grid, block, sp.lds, stream, p, sp.bursts);      \
+      } else {                                                                                                           \
+        return set_error(MI355Q_EINVAL, "w4a16_stream_rows: no whole-row kernel for %d subtiles x %d chunks", sp.ns, sp.cpw);  \
+      }                                                                                                                  \
+    } else {                                                                                                             \
+      if (p.zc) hipLaunchKernelGGL((w4a16_stream_rows_kernel<DT, NS_, CPW_, true, true>), grid, block, sp.lds, stream, p, sp.bursts);  \
+      else hipLaunchKernelGGL((w4a16_stream_rows_kernel<DT, NS_, CPW_, false, true>), grid, block, sp.lds, stream, p, sp.bursts);      \
+    }                                                                                                                    \
     return check_launch("w4a16_stream_rows_kernel");                                                                     \
   }
   MI355Q_SRR(2, 1) MI355Q_SRR(2, 2) MI355Q_SRR(2, 4) MI355Q_SRR(7, 1)
