@@ -216,9 +216,14 @@ int mi355q_w4a16_gemm_add_rms_norm(const void* x, int ldx, const void* residual_
  * Requires G % 128 == 0 and N a multiple of 256 (448 for 112-wide strips):
  * mi355q_w4a16_mm_supported(N, K, G, tile) tells; callers fall back to
  * mi355q_w4a16_dequantize + a dense GEMM otherwise.
+ * mi355q_w4a16_mm_min_rows(N, K, G, tile): the row count from which this entry is the faster one
+ * for the weight (17; 13 on 112-wide strips, where the few-row GEMV entries take a second pass
+ * over the weights) -- the reference draws the same line inside its dispatch heuristics
+ * (gptq exllama: reconstruct above 50 rows, q_gemm.cu:1509; awq: 256 tokens, auto_awq.py:947).
  */
 size_t mi355q_w4a16_mm_workspace_bytes(int M, int N, int K, int G, int tile);
 int mi355q_w4a16_mm_supported(int N, int K, int G, int tile);
+int mi355q_w4a16_mm_min_rows(int N, int K, int G, int tile);
 int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const void* scales, const void* zc,
                     const void* bias, void* c, int M, int N, int K, int G, int tile, int act_dtype,
                     int silu_pairs, void* workspace, size_t workspace_bytes, mi355q_stream_t stream);

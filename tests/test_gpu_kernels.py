@@ -1656,6 +1656,8 @@ def test_sample_topk_topp_vs_oracle(V, B):
     (32, 4096, 6144, 128, 32, True, orc.BF16, False),      # 25+ rows: activation rows fetched whole, fragments through LDS
     (27, 2048, 6144, 128, 32, False, orc.FP16, False),     # ... ragged second row tile, fp16
     (29, 2048, 7168, 128, 112, True, orc.BF16, False),     # ... 112-wide strips with zero points (two subtile passes)
+    (14, 2048, 7168, 128, 112, False, orc.BF16, True),     # 112-wide strips are streamed from 13 rows on (one real row tile)
+    (13, 4096, 7168, 128, 112, True, orc.FP16, False),
 ])
 def test_w4a16_stream_rows_vs_oracle(M, K, N, G, tile, awq, dt, silu):
     """Decode batches beyond the 16-row kernels: every strip streamed once by one workgroup, activations

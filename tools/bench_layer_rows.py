@@ -1,6 +1,6 @@
 """Per-launch time of the four projections of a Llama-3-8B layer at a decode batch of M rows (default 32), called the
-way the runner calls them from 17 rows on: qkv and gate_up (+SiLU pairs) on the tiled / streaming kernels, o and
-down with the residual add and the next norm fused behind their K-slice merge.  Each is a graph of back-to-back
+way the runner calls them from two rows on (from 17 rows: qkv and gate_up (+SiLU pairs) on the tiled / streaming kernels, o and
+down with the residual add and the next norm fused behind their K-slice merge where a merge exists).  Each is a graph of back-to-back
 launches over 32 distinct weight sets, so that no launch finds its weights cached.
 
     python tools/bench_layer_rows.py [M ...]
@@ -35,10 +35,22 @@ def run(M):
     x = (torch.randn((M, H), device=dev, generator=g) * 0.25).to(torch.bfloat16)
     res = (torch.randn((M, H), device=dev, generator=g) * 0.25).to(torch.bfloat16)
     act = (torch.randn((M, I), device=dev, generator=g) * 0.25).to(torch.bfloat16)
+    def proj_norm(a, w):   # as the runner: one fused op where the K-slice merge can take the norm, else two launches
+        if ops.w4a16_mm_add_rms_norm_supported(M, w):
+            return ops.w4a16_mm_add_rms_norm(a, w, res, nw, 1e-5)
+        o = ops.w4a16_gemm(a, w)
+        ops.fused_add_rms_norm(o, res, nw, 1e-5)
+        return o
+
+    def gate_up(w):
+        if M >= ops.mm_min_tokens(w):
+            return ops.w4a16_mm(x, w, silu_pairs=True)
+        return ops.w4a16_gate_up_silu(x, None, None, 1e-5, w, add_norm=False)[0]
+
     cases = [("qkv", W["qkv"], lambda w: ops.w4a16_gemm(x, w)),
-             ("o+norm", W["o"], lambda w: ops.w4a16_mm_add_rms_norm(x, w, res, nw, 1e-5)),
-             ("gate_up+silu", W["gate_up"], lambda w: ops.w4a16_mm(x, w, silu_pairs=True)),
-             ("down+norm", W["down"], lambda w: ops.w4a16_mm_add_rms_norm(act, w, res, nw, 1e-5))]
+             ("o+norm", W["o"], lambda w: proj_norm(x, w)),
+             ("gate_up+silu", W["gate_up"], gate_up),
+             ("down+norm", W["down"], lambda w: proj_norm(act, w))]
     out, total = [], 0.0
     for name, ws, fn in cases:
         for w in ws[:3]:

@@ -1652,8 +1652,9 @@ static RowsPlan plan_rows(int M, int N, int K, int G, bool has_zc) {
   if (G % 128 || K % 128 || N % (16 * ROWS_SPB)) return rp;
   const int chunks = K / 128, gchunks = G / 128, vstrips = N / (16 * ROWS_SPB);
   int best_score = -1;
+  const int max_wgs = env_int("MI355Q_ROWS_MAX_WGS", 320), fill_cap = env_int("MI355Q_ROWS_FILL", 256);
   for (int s = 1; s <= 16; s++) {
-    if (chunks % s || vstrips * s > 320) continue;
+    if (chunks % s || vstrips * s > max_wgs) continue;
     const int cps = chunks / s;
     for (int nw = 8; nw >= 1; nw--) {
       if (cps % nw) continue;
@@ -1661,7 +1662,7 @@ static RowsPlan plan_rows(int M, int N, int K, int G, bool has_zc) {
       for (int cpw = 4; cpw >= 2; cpw -= 2) {
         if (per % cpw) continue;
         // prefer the slice count that fills the chip, then bytes in flight per CU, then waves
-        const int fill = std::min(vstrips * s, 256);
+        const int fill = std::min(vstrips * s, fill_cap);
         const int score = fill * 1000 + std::min(nw * cpw, 32) * 10 + nw;
         if (score > best_score) {
           best_score = score;
@@ -2417,7 +2418,11 @@ struct StreamRowsPlan {
 static StreamRowsPlan plan_stream_rows(int M, int N, int K, int G, int sw) {
   StreamRowsPlan sp{false, 0, 0, 0, 0, false, false};
   const int max_rows = env_int("MI355Q_STREAM_ROWS_MAX", 32);   // looked up per call: mi355q_set_option switches it
-  if (M < 17 || M > max_rows || G % 128 || K % 128 || sw % 16 || N % sw) return sp;
+  // 112-wide strips from 13 rows on: the single-pass GEMV kernel holds 12 activation rows of K = 4096 and takes a
+  // second pass over the weights beyond (gate_up + SiLU at 14 / 16 rows: 27.3 / 27.5 us, streamed 16.7 / 16.0; at 12
+  // rows 15.5 against 16.6).  32-wide strips gain nothing below 17 rows (qkv at 16 rows 9.05 against 9.13).
+  const int min_rows = env_int("MI355Q_STREAM_ROWS_MIN", sw == 112 ? 13 : 17);
+  if (M < min_rows || M > max_rows || G % 128 || K % 128 || sw % 16 || N % sw) return sp;
   const int ns = sw / 16, chunks = K / 128;
   // Every workgroup reads all M x K activations, so the activation traffic is (N / sw) x M x K x 2 bytes:
   // on 16-wide strips that is 8x the weights at 32 rows (measured: down_proj 14336x4096 31 us against 21 us
@@ -2567,7 +2572,12 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw, bool grouped = false) 
   // decode batches (32-row tiles) on a short K: 128-wide workgroups need half the K-slices to fill the chip, and
   // with 32 chunks the slices are what the launch costs (o_proj 4096 x 4096 at 32 rows, with its merge-and-norm:
   // 15.2 -> 12.3 us; down_proj, 112 chunks, 19.7 -> 21.1 and keeps the wide form)
-  if (mm_rt(M) == 2 && ns == 1 && K / 128 <= 32 && !grouped) spw = 2;
+  // A long K (down_proj, 112 chunks) takes them too, with K-slices until two workgroups share a CU: the 256-wide form
+  // holds one chunk in flight per SIMD (1 workgroup of 224 registers per lane on a CU), the 128-wide one (112
+  // registers) two; down_proj + merge-and-norm at 32 / 24 / 17 rows 19.7 / 18.6 / 18.6 -> 18.2 / 17.8 / 17.5 us with
+  // 16 slices of 7 chunks on 512 workgroups (8 slices of 14 chunks: 21.1)
+  const bool rt2_narrow = mm_rt(M) == 2 && ns == 1 && !grouped;
+  if (rt2_narrow) spw = 2;
   while (spw > 1 && N % (4 * spw * sw)) spw >>= 1;
   if (const int o = env_int("MI355Q_MM_SPW", 0); o > 0 && o <= 4 / ns && (o & (o - 1)) == 0) spw = o;   // experiments
   const int bw = 4 * spw * sw;
@@ -2580,10 +2590,11 @@ static MmPlan plan_mm(int M, int N, int K, int G, int sw, bool grouped = false) 
   // workgroups on it prefers slices of 8+ chunks to more workgroups (measured at 128 rows: qkv 30.2 -> 23.8 us
   // with 4 instead of 8 slices, o 21.4 -> 20.7; down_proj, whose slices stay long, keeps its 8: 33.4 vs 43.4).
   const bool ksplit = mm_rt(M) == MM_RT && mm_ring_form(ns, spw, grouped, M, 0, N / bw) == RING_K;
-  const long want = 200;
+  const long want = rt2_narrow && spw == 2 && chunks > 32 ? 400 : 200;
   int s = 1;
   while (tiles * s < want && s < 16 && chunks % (s * 2) == 0 && chunks / (s * 2) >= 2) {
     if (ksplit && tiles * s >= 120 && chunks / (s * 2) < 8) break;
+    if (want > 200 && tiles * s >= 200 && chunks / (s * 2) < 7) break;   // the second workgroup per CU only on slices of 7+ chunks
     s *= 2;
   }
   if (tiles * s < want) {   // odd factors of the chunk count (K = 14336 = 128 * 112 = 128 * 16 * 7)
@@ -3065,6 +3076,14 @@ extern "C" size_t mi355q_w4a16_mm_workspace_bytes(int M, int N, int K, int G, in
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const MmPlan mp = plan_mm(M, N, K, G, tile);
   return mp.ok ? mp.ws : 0;
+}
+
+extern "C" int mi355q_w4a16_mm_min_rows(int N, int K, int G, int tile) {
+  if (G <= 0) G = K;
+  if (N <= 0 || K <= 0 || tile <= 0 || N % tile || !tile_ok(tile, K, G)) return 17;
+  for (int m = 2; m < 17; m++)
+    if (plan_stream_rows(m, N, K, G, tile).ok) return m;
+  return 17;
 }
 
 extern "C" int mi355q_w4a16_mm_supported(int N, int K, int G, int tile) {

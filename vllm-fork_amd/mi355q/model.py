@@ -486,7 +486,7 @@ class LlamaRunner:
 
         if self.quant != "none" and L["gate_up"].w.pair_halves:
             gu_w = L["gate_up"].w
-            tiled = ops.MM_MIN_TOKENS <= T <= ops.MM_MAX_TOKENS and ops._mm_supported(gu_w)
+            tiled = ops.mm_min_tokens(gu_w) <= T <= ops.MM_MAX_TOKENS and ops._mm_supported(gu_w)
             if T < ops.MM_MIN_TOKENS or tiled:
                 # SiluAndMul in the gate_up epilogue (and, for a few tokens, the norm in its prologue)
                 if fuse_norm:

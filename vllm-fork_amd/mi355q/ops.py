@@ -186,6 +186,13 @@ def _mm_supported(w: PackedW4) -> bool:
     return bool(_lib.lib().mi355q_w4a16_mm_supported(w.N, w.K, w.G, w.tile))
 
 
+def mm_min_tokens(w: PackedW4) -> int:
+    """Row count from which `w4a16_mm` beats the few-row entries on this weight: MM_MIN_TOKENS, or fewer where the
+    streaming rows kernel takes over earlier (112-wide strips: the single-pass GEMV kernel runs out of LDS for the
+    activation rows at 13)."""
+    return min(MM_MIN_TOKENS, int(_lib.lib().mi355q_w4a16_mm_min_rows(w.N, w.K, w.G, w.tile)))
+
+
 def w4a16_mm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, silu_pairs: bool = False,
              out: torch.Tensor | None = None) -> torch.Tensor:
     """[tokens, K] @ dequant(w) for prompt-sized token counts on the tiled matrix-core kernel: the packed

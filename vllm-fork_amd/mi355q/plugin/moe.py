@@ -254,7 +254,7 @@ def fused_experts(x: torch.Tensor, w13: ops.PackedMoeW4, w2: ops.PackedMoeW4, to
             w13_e = w13.expert(e)
             if not w13.pair_halves:
                 ops.silu_and_mul(act, ops.w4a16_gemm(x, w13_e))
-            elif T < ops.MM_MIN_TOKENS or not ops._mm_supported(w13_e):   # SiluAndMul in the projection's epilogue
+            elif T < ops.mm_min_tokens(w13_e) or not ops._mm_supported(w13_e):   # SiluAndMul in the projection's epilogue
                 act, _ = ops.w4a16_gate_up_silu(x, None, None, 0.0, w13_e, add_norm=False)
             else:
                 act = ops.w4a16_mm(x, w13_e, silu_pairs=True)
