@@ -30,6 +30,13 @@ def test_prompt_gemm_random_shapes(seed):
     assert _tool("fuzz_mm").run(20, seed, verbose=False) == 0
 
 
+@pytest.mark.parametrize("seed", [13, 14])
+def test_decode_batch_gemm_random_shapes(seed):
+    """13 to 32 rows through the many-row entry on wide layers: the streaming rows kernel in its forms (fragments
+    gathered per lane or whole rows through LDS, 32- and 112-wide strips) and the 32-row tiles with K-slices."""
+    assert _tool("fuzz_mm").run(16, seed, verbose=False, decode_batches=True) == 0
+
+
 @pytest.mark.parametrize("seed", [21, 22])
 def test_prompt_attention_random_configurations(seed):
     """Bars of test_paged_prefill_attention_vs_oracle for each kernel (partitioned 3e-3, running softmax 4e-3, fp8 cache 1e-2)."""

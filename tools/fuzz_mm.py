@@ -1,5 +1,7 @@
 """Random shapes through ops.w4a16_mm (every form of the prompt kernel the planner picks) against the oracle.
-python tools/fuzz_mm.py [cases] [seed]"""
+python tools/fuzz_mm.py [cases] [seed] [batches]
+With a third argument: decode batches of 13 to 32 rows on layers wide enough for the streaming rows kernel (gathered
+and whole-row activation fetch, one- and two-chunk rings) and the 32-row tiles with their K-slices."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vllm-fork_amd")); sys.path.insert(0, ROOT)
@@ -9,7 +11,7 @@ from mi355q import ops, _lib
 DEV = "cuda:0"
 
 
-def run(cases, seed, verbose=True):
+def run(cases, seed, verbose=True, decode_batches=False):
     rng = np.random.default_rng(seed)
     _print = print if verbose else (lambda *a, **k: None)
     bad = 0
@@ -20,6 +22,11 @@ def run(cases, seed, verbose=True):
         K = 128 * int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 28]))
         G = int(rng.choice([128, K])) if K % 128 == 0 else 128
         M = int(rng.choice([17, 31, 33, 40, 48, 64, 65, 100, 128, 129, 200, 256, 300, 511, 640]))
+        if decode_batches:
+            N = bw * int(rng.choice([4, 8, 16, 24]))
+            K = 128 * int(rng.choice([8, 16, 24, 32, 56, 112]))
+            G = int(rng.choice([128, 128, 256, K]))
+            M = int(rng.choice([13, 14, 16, 17, 20, 24, 25, 27, 29, 31, 32]))
         awq = bool(rng.integers(0, 2))
         dt = orc.BF16 if rng.integers(0, 3) else orc.FP16
         tdt = torch.bfloat16 if dt == orc.BF16 else torch.float16
@@ -50,6 +57,7 @@ def run(cases, seed, verbose=True):
 
 
 if __name__ == "__main__":
-    n_bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    n_bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+                decode_batches=len(sys.argv) > 3)
     print("FAILURES", n_bad)
     sys.exit(1 if n_bad else 0)
