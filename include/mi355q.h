@@ -224,6 +224,11 @@ int mi355q_w4a16_gemm_add_rms_norm(const void* x, int ldx, const void* residual_
 size_t mi355q_w4a16_mm_workspace_bytes(int M, int N, int K, int G, int tile);
 int mi355q_w4a16_mm_supported(int N, int K, int G, int tile);
 int mi355q_w4a16_mm_min_rows(int N, int K, int G, int tile);
+/* 1 when mi355q_w4a16_mm serves M rows of this weight on the kernel that streams every strip once and needs no
+ * K-slices (decode batches): a caller that would otherwise fuse the residual add and the norm behind the K-slice
+ * merge (mi355q_w4a16_mm_add_rms_norm) is faster with this entry plus mi355q_fused_add_rms_norm on 16-wide strips.
+ * Part of the same dispatch heuristics as above (q_gemm.cu:1509, auto_awq.py:947). */
+int mi355q_w4a16_mm_streams(int M, int N, int K, int G, int tile);
 int mi355q_w4a16_mm(const void* a, int lda, const void* packed, const void* scales, const void* zc,
                     const void* bias, void* c, int M, int N, int K, int G, int tile, int act_dtype,
                     int silu_pairs, void* workspace, size_t workspace_bytes, mi355q_stream_t stream);

@@ -36,7 +36,7 @@ def run(M):
     res = (torch.randn((M, H), device=dev, generator=g) * 0.25).to(torch.bfloat16)
     act = (torch.randn((M, I), device=dev, generator=g) * 0.25).to(torch.bfloat16)
     def proj_norm(a, w):   # as the runner: one fused op where the K-slice merge can take the norm, else two launches
-        if ops.w4a16_mm_add_rms_norm_supported(M, w):
+        if ops.w4a16_mm_add_rms_norm_preferred(M, w):
             return ops.w4a16_mm_add_rms_norm(a, w, res, nw, 1e-5)
         o = ops.w4a16_gemm(a, w)
         ops.fused_add_rms_norm(o, res, nw, 1e-5)

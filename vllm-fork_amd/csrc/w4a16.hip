@@ -2217,9 +2217,8 @@ __global__ __launch_bounds__(512) void w4a16_stream_rows_kernel(const MmParams p
   // row costs next to nothing).  XLDS: the rows are fetched whole (4 rows x 256 B per instruction), written to the
   // wave's own 8 KiB of LDS (piece p of row r at position p ^ (r & 15): conflict-free both ways) and read back as
   // fragments -- same values in the same lanes.  The staging areas lie over the slices of the final sum, which the
-  // running sums in registers leave unused until the end.  It pays when the second row tile is mostly real rows
-  // (us at 17 / 24 / 32 rows, gathered -> staged: qkv 9.2 / 10.4 / 12.3 -> 10.4 / 10.6 / 10.9, gate_up 16.5 / 18.2 /
-  // 20.0 -> 18.5 / 17.9 / 19.0).
+  // running sums in registers leave unused until the end.  The plan says from which row count on it pays for a strip
+  // width (at 32 rows, gathered -> staged: qkv 12.3 -> 9.3 us, gate_up 20.0 -> 19.0).
   unsigned char* xst = reinterpret_cast<unsigned char*>(red) + wave * 8192;
   const unsigned char* xbytes = reinterpret_cast<const unsigned char*>(p.x);
   uint32_t xoff[8];   // byte offset of piece ml of row 4 t + kq
@@ -2420,8 +2419,10 @@ static StreamRowsPlan plan_stream_rows(int M, int N, int K, int G, int sw) {
   const int max_rows = env_int("MI355Q_STREAM_ROWS_MAX", 32);   // looked up per call: mi355q_set_option switches it
   // 112-wide strips from 13 rows on: the single-pass GEMV kernel holds 12 activation rows of K = 4096 and takes a
   // second pass over the weights beyond (gate_up + SiLU at 14 / 16 rows: 27.3 / 27.5 us, streamed 16.7 / 16.0; at 12
-  // rows 15.5 against 16.6).  32-wide strips gain nothing below 17 rows (qkv at 16 rows 9.05 against 9.13).
-  const int min_rows = env_int("MI355Q_STREAM_ROWS_MIN", sw == 112 ? 13 : 17);
+  // rows 15.5 against 16.6).  16-wide strips on a short K likewise (o_proj at 13 / 16 rows, with the stand-alone
+  // add-and-norm: 10.9 / 11.2 -> 10.1 / 9.8 us).  32-wide strips gain nothing below 17 rows (qkv at 16 rows 9.05
+  // against 9.13 gathered, 8.65 with the whole-row fetch; 8.7 at 13-14 rows either way).
+  const int min_rows = env_int("MI355Q_STREAM_ROWS_MIN", (sw == 112 || sw == 16) ? 13 : 17);
   if (M < min_rows || M > max_rows || G % 128 || K % 128 || sw % 16 || N % sw) return sp;
   const int ns = sw / 16, chunks = K / 128;
   // Every workgroup reads all M x K activations, so the activation traffic is (N / sw) x M x K x 2 bytes:
@@ -2429,23 +2430,30 @@ static StreamRowsPlan plan_stream_rows(int M, int N, int K, int G, int sw) {
   // for the tiled kernel with its K-slice merge, o_proj 12.4 + norm against 7.4 + merge-and-norm 6) -- the
   // tiled kernel shares one activation tile between 256 channels and keeps those layers.  On 32- and
   // 112-wide strips streaming wins (qkv 12.7 against 11.7 + 6.4, gate_up 23.5 against 23.2 + 5.6).
+  // With the whole-row fetch a short K changes that for 16-wide strips: o_proj 4096 x 4096 streamed + stand-alone
+  // add-and-norm 10.5 / 10.2 / 10.2 us at 32 / 24 / 17 rows against 12.4 / 11.7 / 11.4 for the tiled kernel with its
+  // merge-and-norm (gathered fragments: 14.4 / 12.7 at 32 / 25); down_proj (K = 14336) 33 us against 19.
+  const int regacc = env_int("MI355Q_STREAM_ROWS_REGACC", 2);
+  // whole-row activation fetch (looked up per call): 16-wide strips always, 32-wide from 17 rows on (with the two-chunk ring qkv
+  // 9.4 / 9.8 / 10.4 -> 9.0 / 8.9 / 8.9 us at 17 / 20 / 24 rows), 112-wide strips from 23 (gate_up 16.1 / 16.6 / 17.8 ->
+  // 17.8 / 17.5 / 17.3: the two subtile passes cost more than the gather of a second row tile that is mostly one row)
+  const bool want_xlds = M >= env_int("MI355Q_STREAM_ROWS_XLDS_MIN", ns == 7 ? 23 : (ns == 1 ? 13 : 17));
+  const bool narrow_ok = ns == 1 && want_xlds && regacc >= 1 && chunks <= 32;
   const int min_ns = env_int("MI355Q_STREAM_ROWS_MIN_NS", 2);
-  if (ns < min_ns || chunks % 8 || (long)(N / sw) < 64) return sp;
+  if ((ns < min_ns && !narrow_ok) || chunks % 8 || (long)(N / sw) < 64) return sp;
   const int per = chunks / 8;
   // Running sums in registers: 32-wide strips, and 112-wide strips with a one-chunk ring (two chunks of ring and two
   // sets of sums do not fit in 256 registers).  gate_up at 17 / 32 rows 19.6 -> 16.7 / 21.8 -> 20.3 us; qkv does not
   // move (12.2 us: bound by the activation fragments every workgroup reads from L2, 5 x its weights).
   // MI355Q_STREAM_ROWS_REGACC = 0 keeps the sums in LDS, 1 leaves 112-wide strips on the two-chunk ring.
-  const int regacc = env_int("MI355Q_STREAM_ROWS_REGACC", 2);
-  // whole-row activation fetch from 25 rows on (looked up per call)
-  const bool want_xlds = M >= env_int("MI355Q_STREAM_ROWS_XLDS_MIN", 25);
   const int cands[5] = {8, 7, 4, 2, 1};
   for (int cpw : cands) {
     if (per % cpw || cpw * ns > 16 || !stream_rows_built(ns, cpw)) continue;
     // a four-chunk ring beside the whole-row fetch spills registers (qkv at 32 rows: 10.9 us, 9.3 with two chunks)
     if (want_xlds && regacc >= 1 && ns == 2 && cpw > 2) continue;
     if (regacc == 2 && ns == 7 && cpw != 1) continue;
-    sp.regacc = (regacc >= 1 && ns == 2) || (regacc == 2 && ns == 7 && cpw == 1);
+    if (narrow_ok && cpw > 4) continue;   // the register-sum kernels of 16-wide strips are built for rings of 1, 2, 4 chunks
+    sp.regacc = (regacc >= 1 && ns == 2) || (regacc == 2 && ns == 7 && cpw == 1) || narrow_ok;
     sp.ok = true; sp.ns = ns; sp.cpw = cpw; sp.bursts = per / cpw;
     // the eight 8 KiB staging areas lie over the slices
     sp.xlds = sp.regacc && want_xlds;
@@ -2480,7 +2488,7 @@ static int launch_stream_rows(const MmParams& p, const StreamRowsPlan& sp, hipSt
     }                                                                                                                    \
     return check_launch("w4a16_stream_rows_kernel");                                                                     \
   }
-  MI355Q_SRR(2, 1) MI355Q_SRR(2, 2) MI355Q_SRR(2, 4) MI355Q_SRR(7, 1)
+  MI355Q_SRR(2, 1) MI355Q_SRR(2, 2) MI355Q_SRR(2, 4) MI355Q_SRR(7, 1) MI355Q_SRR(1, 1) MI355Q_SRR(1, 2) MI355Q_SRR(1, 4)
 #undef MI355Q_SRR
   MI355Q_SR(1, 1) MI355Q_SR(1, 2) MI355Q_SR(1, 4) MI355Q_SR(1, 7) MI355Q_SR(1, 8)
   MI355Q_SR(2, 1) MI355Q_SR(2, 2) MI355Q_SR(2, 4)
@@ -3084,6 +3092,12 @@ extern "C" int mi355q_w4a16_mm_min_rows(int N, int K, int G, int tile) {
   for (int m = 2; m < 17; m++)
     if (plan_stream_rows(m, N, K, G, tile).ok) return m;
   return 17;
+}
+
+extern "C" int mi355q_w4a16_mm_streams(int M, int N, int K, int G, int tile) {
+  if (G <= 0) G = K;
+  if (M <= 0 || N <= 0 || K <= 0 || tile <= 0 || N % tile || !tile_ok(tile, K, G)) return 0;
+  return plan_stream_rows(M, N, K, G, tile).ok ? 1 : 0;
 }
 
 extern "C" int mi355q_w4a16_mm_supported(int N, int K, int G, int tile) {

@@ -54,6 +54,7 @@ _SIGS = {
     "mi355q_w4a16_mm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_vp, c_sz, c_vp]),
     "mi355q_w4a16_mm_min_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "mi355q_w4a16_mm_streams": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mi355q_w4a16_mm_add_rms_norm_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "mi355q_w4a16_mm_add_rms_norm_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "mi355q_w4a16_mm_add_rms_norm": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_int, c_int,

@@ -408,7 +408,7 @@ class LlamaRunner:
         as one kernel: the token range of the tiled kernel (or of the K-sliced rows kernel), whole
         projection on this rank."""
         return (self.quant != "none" and not self.tp_collectives and T <= ops.MM_MAX_TOKENS
-                and ops.w4a16_mm_add_rms_norm_supported(T, lin.w))
+                and ops.w4a16_mm_add_rms_norm_preferred(T, lin.w))
 
     def _layer(self, L, li, h, residual, positions, slot_mapping, attend, normed=False, next_norm=None):
         """One decoder layer.  `normed`: h already is RMSNorm(residual) (the previous layer's down

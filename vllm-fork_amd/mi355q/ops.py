@@ -107,7 +107,7 @@ DEQUANT_MATMUL_MIN_TOKENS = 32
 # token range served by the tiled matrix-core W4A16 kernel (below: the decode kernels; above: dequantise
 # once + dense GEMM, compute-bound and best left to the BLAS).  Upper end by measurement on Llama-3-8B
 # (TTFT, tiled / dequantise + BLAS): 900 tokens 19.8 / 21.3 ms, 1024 19.8 / 21.1, 1280 27.5 / 24.5.
-MM_MIN_TOKENS = 17
+MM_MIN_TOKENS = _MM_MIN_TOKENS_DEFAULT = 17
 MM_MAX_TOKENS = int(os.environ.get("MI355Q_MM_MAX_TOKENS", "1024"))
 # Above MM_MAX_TOKENS every call expands the layer's weights into the staging buffer first (a quarter of the
 # route's time at 2048 tokens).  With 288 GB per GPU a deployment may prefer to keep the expanded copy of
@@ -152,7 +152,7 @@ def w4a16_gemm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, s
     M = x2.shape[0]
     if out is not None and (out.shape != (M, w.N) or out.dtype != x.dtype or not out.is_contiguous()):
         raise RuntimeError(f"out must be a contiguous [{M}, {w.N}] tensor of the activation dtype")
-    if MM_MIN_TOKENS <= M <= MM_MAX_TOKENS and not fuse_silu_mul and _mm_supported(w):
+    if M <= MM_MAX_TOKENS and not fuse_silu_mul and M >= mm_min_tokens(w) and _mm_supported(w):
         return w4a16_mm(x2, w, bias, out=out).reshape(x.shape[:-1] + (w.N,))
     if M > DEQUANT_MATMUL_MIN_TOKENS and not torch.cuda.is_current_stream_capturing():
         # many tokens (prompt processing): dequantise once and run a dense GEMM, as the reference
@@ -190,6 +190,8 @@ def mm_min_tokens(w: PackedW4) -> int:
     """Row count from which `w4a16_mm` beats the few-row entries on this weight: MM_MIN_TOKENS, or fewer where the
     streaming rows kernel takes over earlier (112-wide strips: the single-pass GEMV kernel runs out of LDS for the
     activation rows at 13)."""
+    if MM_MIN_TOKENS != _MM_MIN_TOKENS_DEFAULT:   # a caller moved the line (tests of the few-row kernels at every M)
+        return MM_MIN_TOKENS
     return min(MM_MIN_TOKENS, int(_lib.lib().mi355q_w4a16_mm_min_rows(w.N, w.K, w.G, w.tile)))
 
 
@@ -221,6 +223,14 @@ def w4a16_mm(x: torch.Tensor, w: PackedW4, bias: torch.Tensor | None = None, sil
 
 def w4a16_mm_add_rms_norm_supported(tokens: int, w: PackedW4) -> bool:
     return bool(_lib.lib().mi355q_w4a16_mm_add_rms_norm_supported(tokens, w.N, w.K, w.G, w.tile, int(w.zc is not None)))
+
+
+def w4a16_mm_add_rms_norm_preferred(tokens: int, w: PackedW4) -> bool:
+    """The fused projection + add + norm is served AND faster than `w4a16_mm` followed by `fused_add_rms_norm`: not
+    so where the projection streams its 16-wide strips without K-slices (nothing to merge, o_proj at 17-32 rows)."""
+    if not w4a16_mm_add_rms_norm_supported(tokens, w):
+        return False
+    return not (w.tile == 16 and _lib.lib().mi355q_w4a16_mm_streams(tokens, w.N, w.K, w.G, w.tile))
 
 
 def w4a16_mm_add_rms_norm(x: torch.Tensor, w: PackedW4, residual: torch.Tensor, norm_weight: torch.Tensor,
