@@ -30,9 +30,10 @@ def test_greedy_tokens_match_oracle(quant, kv, model, monkeypatch):
     assert got[0] == want[0] and sum(g == w for g, w in zip(got, want)) >= 4
 
 
-@pytest.mark.parametrize("batch,quant,kv", [(8, "gptq", "auto"), (20, "awq", "auto"), (40, "gptq", "auto"), (48, "awq", "fp8")])
+@pytest.mark.parametrize("batch,quant,kv", [(8, "gptq", "auto"), (14, "gptq", "auto"), (20, "awq", "auto"), (28, "awq", "fp8"),
+                                            (40, "gptq", "auto"), (48, "awq", "fp8")])
 def test_batch_decode_tokens_match_oracle(batch, quant, kv, monkeypatch):
-    """Decode batches through the kernels that serve several rows (the 5-16-row kernel, the 17-32-row forms, the
+    """Decode batches through the kernels that serve several rows (the 5-16-row kernel, the streaming forms of 13-32 rows, the
     tiled kernel with its fused residual-add + norm and RoPE + cache-write consumers from 33 rows on), under the
     captured graph, token for token against the oracle model."""
     from mi355q import ops
